@@ -1,0 +1,153 @@
+/*
+ * lv_attention.h — C ABI of the MI355X (gfx950) paged-attention library, liblvattn.so.
+ *
+ * The three compute entry points replace the three device calls that light-vllm's
+ * Attention.forward makes (reference: lightvllm/layers/attention.py):
+ *
+ *   lv_store_kvcache   <- store_kvcache_kernel + store_kvcache      attention.py:9-52, 54-108
+ *   lv_prefill_attn    <- flash_attn_varlen_func(... causal, block_table)   attention.py:159-165
+ *   lv_decode_attn     <- flash_attn_with_kvcache(... cache_seqlens, block_table)   attention.py:172-175
+ *
+ * Conventions
+ *   - Every pointer except `workspace` sizes is a DEVICE pointer on the current HIP device.
+ *   - All tensors are bf16 (2 bytes per element) unless stated; index tensors are int32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Every call only enqueues work on `stream`: no host synchronisation, no allocation,
+ *     safe to capture into a hipGraph.
+ *   - Return value: LV_OK (0) or a negative LV_ERR_* code; lv_last_error() returns a
+ *     thread-local human-readable message for the last failing call.
+ *   - head_dim must be 128 (every Qwen3 size). Other values return LV_ERR_UNSUPPORTED.
+ *   - Strides are in ELEMENTS (bf16), as torch's Tensor.stride() reports them.
+ */
+#ifndef LV_ATTENTION_H
+#define LV_ATTENTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LV_OK 0
+#define LV_ERR_INVALID_ARGUMENT (-1)
+#define LV_ERR_UNSUPPORTED (-2)
+#define LV_ERR_LAUNCH (-3)
+#define LV_ERR_WORKSPACE (-4)
+
+#define LV_ABI_VERSION 1
+
+typedef void* lv_stream_t;
+
+/* ABI version of the loaded library (LV_ABI_VERSION at build time). */
+int lv_abi_version(void);
+
+/* Static description of an LV_ERR_* code. Never NULL. */
+const char* lv_error_string(int code);
+
+/* Message recorded by the last failing call on this thread ("" if none). */
+const char* lv_last_error(void);
+
+/*
+ * Scatter the K/V rows of this step's new tokens into the paged cache.
+ * Reference: store_kvcache (attention.py:54-108) launching store_kvcache_kernel (attention.py:9-52).
+ *
+ *   for i in [0, num_tokens):  s = slot_mapping[i]
+ *       k_cache[s, :] = key[i, :]      (row = num_kv_heads * head_dim contiguous elements)
+ *       v_cache[s, :] = value[i, :]
+ *
+ *   key, value       [num_tokens, num_kv_heads, head_dim]; last two dims contiguous,
+ *                    row strides key_stride0 / value_stride0 free (value is normally a view
+ *                    into the fused qkv activation; models/qwen3.py:95). 16-byte aligned rows.
+ *   k_cache, v_cache [num_slots, num_kv_heads * head_dim] contiguous
+ *                    (= [num_blocks, block_size, num_kv_heads, head_dim]; attention.py:96).
+ *   slot_mapping     int32 [num_tokens]. Entries < 0 or >= num_slots are SKIPPED (the reference
+ *                    kernel has no such guard; -1 is the padding value hipGraph replay uses).
+ * Bit-exact copy; offsets are 64-bit (slot * row exceeds 2^31 elements on a 288 GB cache).
+ * Duplicate slots inside one call are last-writer-wins in unspecified order.
+ */
+int lv_store_kvcache(const void* key, const void* value,
+                     int64_t key_stride0, int64_t value_stride0,
+                     void* k_cache, void* v_cache,
+                     const int32_t* slot_mapping,
+                     int64_t num_tokens, int num_kv_heads, int head_dim,
+                     int64_t num_slots, lv_stream_t stream);
+
+/*
+ * Variable-length causal self-attention over a packed batch (prefill).
+ * Reference call site: flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q,
+ * max_seqlen_k, softmax_scale, causal=True, block_table) — attention.py:159-165.
+ *
+ *   q   [total_q, num_heads, head_dim]      row stride q_stride0
+ *   o   [total_q, num_heads, head_dim]      row stride o_stride0
+ *   cu_seqlens_q / cu_seqlens_k  int32 [batch + 1] (prefix sums of Lq_b / Lk_b)
+ *
+ *   Packed mode (block_table == NULL): k, v are [total_k, num_kv_heads, head_dim] with row
+ *     strides k_stride0 / v_stride0; sequence b owns rows cu_seqlens_k[b] .. cu_seqlens_k[b+1].
+ *   Paged mode (block_table != NULL): k, v are the paged caches [num_blocks, block_size,
+ *     num_kv_heads, head_dim] contiguous (k_stride0 == v_stride0 == num_kv_heads * head_dim);
+ *     key t of sequence b lives at row block_table[b * block_table_stride + t / block_size]
+ *     * block_size + t % block_size. Entries past ceil(Lk_b / block_size) are never read
+ *     (the reference pads them with -1; model_runner.py:266-267).
+ *
+ * Semantics: per sequence b and query head h (kv head h / (num_heads / num_kv_heads)),
+ *   O = softmax(scale * Q K^T + causal) V with the causal mask bottom-right aligned:
+ *   query row r (0-based in the sequence's Lq_b rows) sees keys t <= r + (Lk_b - Lq_b).
+ *   bf16 inputs, fp32 scores / softmax statistics / accumulation, bf16 output.
+ *   A query row that sees no key (Lk_b < Lq_b rows) is written as zeros.
+ * max_seqlen_q bounds the grid (rows beyond a sequence's Lq_b exit early); max_seqlen_k is
+ * accepted for signature parity and only validated.
+ */
+int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
+                    int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
+                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                    int batch, int max_seqlen_q, int max_seqlen_k,
+                    const int32_t* block_table, int block_table_stride, int block_size,
+                    int num_heads, int num_kv_heads, int head_dim, float scale,
+                    lv_stream_t stream);
+
+/*
+ * Split count lv_decode_attn will use when called with num_splits == 0, for these static
+ * shapes (it never depends on device data, so it is stable under hipGraph replay).
+ */
+int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq);
+
+/*
+ * Bytes of device workspace lv_decode_attn needs for (batch, num_heads, num_splits).
+ * 0 when num_splits <= 1. head_dim must be 128.
+ */
+size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num_splits);
+
+/*
+ * Single-query-token attention over the paged KV cache (decode).
+ * Reference call site: flash_attn_with_kvcache(q.unsqueeze(1), k_cache, v_cache,
+ * cache_seqlens=context_lens, block_table=block_tables, softmax_scale, causal=True)
+ * — attention.py:172-175.
+ *
+ *   q, o          [batch, num_heads, head_dim], row strides q_stride0 / o_stride0
+ *   k_cache, v_cache  [num_blocks, block_size, num_kv_heads, head_dim] contiguous
+ *   context_lens  int32 [batch]; sequence b attends to cache tokens [0, context_lens[b]),
+ *                 which already include the token stored by this step's lv_store_kvcache.
+ *                 context_lens[b] == 0 (graph padding rows) writes a zero output row.
+ *   block_table   int32 [batch, block_table_stride], >= max_blocks_per_seq valid columns;
+ *                 entries past ceil(context_lens[b] / block_size) are never read.
+ *   block_size    tokens per block; a multiple of 32.
+ *   num_splits    KV splits per (sequence, kv head): 0 = library heuristic
+ *                 (lv_decode_num_splits), 1 = single pass, n > 1 = split-KV with a merge
+ *                 pass through `workspace` (>= lv_decode_workspace_bytes bytes, 16-byte aligned).
+ *
+ * bf16 inputs, fp32 scores / online softmax / accumulation, bf16 output.
+ */
+int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* o,
+                   int64_t q_stride0, int64_t o_stride0,
+                   const int32_t* context_lens,
+                   const int32_t* block_table, int block_table_stride,
+                   int batch, int max_blocks_per_seq, int block_size,
+                   int num_heads, int num_kv_heads, int head_dim, float scale,
+                   void* workspace, size_t workspace_bytes, int num_splits,
+                   lv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LV_ATTENTION_H */

@@ -1,0 +1,197 @@
+// C-ABI entry points of liblvattn.so (declared in include/lv_attention.h): argument validation
+// on the host, then stream-ordered kernel launches. Nothing here synchronises or allocates.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "lv_kernels.h"
+
+namespace lv {
+
+static thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kMaxSplits = 128;
+constexpr int kTargetWorkgroups = 1024;  // 256 CUs x 4 resident 256-thread workgroups
+
+static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq) {
+  const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
+  if (units <= 0 || max_blocks_per_seq <= 1) return 1;
+  if (units >= kTargetWorkgroups) return 1;
+  int64_t n = (kTargetWorkgroups + units - 1) / units;
+  if (n > max_blocks_per_seq) n = max_blocks_per_seq;
+  if (n > kMaxSplits) n = kMaxSplits;
+  return n < 1 ? 1 : static_cast<int>(n);
+}
+
+}  // namespace lv
+
+using namespace lv;
+
+extern "C" {
+
+int lv_abi_version(void) { return LV_ABI_VERSION; }
+
+const char* lv_error_string(int code) {
+  switch (code) {
+    case LV_OK: return "ok";
+    case LV_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case LV_ERR_UNSUPPORTED: return "unsupported configuration";
+    case LV_ERR_LAUNCH: return "kernel launch failed";
+    case LV_ERR_WORKSPACE: return "workspace too small or misaligned";
+    default: return "unknown error";
+  }
+}
+
+const char* lv_last_error(void) { return g_last_error; }
+
+int lv_store_kvcache(const void* key, const void* value, int64_t key_stride0,
+                     int64_t value_stride0, void* k_cache, void* v_cache,
+                     const int32_t* slot_mapping, int64_t num_tokens, int num_kv_heads,
+                     int head_dim, int64_t num_slots, lv_stream_t stream) {
+  if (num_tokens < 0 || num_kv_heads <= 0 || head_dim <= 0 || num_slots < 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "store_kvcache: negative size");
+  if (num_tokens == 0 || num_slots == 0) return LV_OK;
+  if (!key || !value || !k_cache || !v_cache || !slot_mapping)
+    return fail(LV_ERR_INVALID_ARGUMENT, "store_kvcache: null pointer");
+  const int64_t row = static_cast<int64_t>(num_kv_heads) * head_dim;
+  if (row % 8 != 0) return fail(LV_ERR_UNSUPPORTED, "store_kvcache: row of %lld elements is not a multiple of 8", (long long)row);
+  if (row > INT32_MAX) return fail(LV_ERR_UNSUPPORTED, "store_kvcache: row too long");
+  if (key_stride0 < row || value_stride0 < row)
+    return fail(LV_ERR_INVALID_ARGUMENT, "store_kvcache: row stride smaller than num_kv_heads*head_dim");
+  if (key_stride0 % 8 != 0 || value_stride0 % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "store_kvcache: row strides must be multiples of 8 elements");
+  if (!aligned16(key) || !aligned16(value) || !aligned16(k_cache) || !aligned16(v_cache))
+    return fail(LV_ERR_UNSUPPORTED, "store_kvcache: pointers must be 16-byte aligned");
+  return launch_store_kvcache(key, value, key_stride0, value_stride0, k_cache, v_cache,
+                              slot_mapping, num_tokens, static_cast<int>(row), num_slots,
+                              static_cast<hipStream_t>(stream));
+}
+
+int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_t q_stride0,
+                    int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
+                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
+                    int max_seqlen_q, int max_seqlen_k, const int32_t* block_table,
+                    int block_table_stride, int block_size, int num_heads, int num_kv_heads,
+                    int head_dim, float scale, lv_stream_t stream) {
+  if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || num_heads <= 0 || num_kv_heads <= 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: negative size");
+  if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "prefill: head_dim %d != 128", head_dim);
+  if (num_heads % num_kv_heads != 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: num_heads %% num_kv_heads != 0");
+  if (batch == 0 || max_seqlen_q == 0) return LV_OK;
+  if (!q || !k || !v || !o || !cu_seqlens_q || !cu_seqlens_k)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: null pointer");
+  const int64_t qrow = static_cast<int64_t>(num_heads) * head_dim;
+  const int64_t krow = static_cast<int64_t>(num_kv_heads) * head_dim;
+  if (q_stride0 < qrow || o_stride0 < qrow || k_stride0 < krow || v_stride0 < krow)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: row stride smaller than heads*head_dim");
+  if ((q_stride0 | k_stride0 | v_stride0 | o_stride0) % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "prefill: row strides must be multiples of 8 elements");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o))
+    return fail(LV_ERR_UNSUPPORTED, "prefill: pointers must be 16-byte aligned");
+  if (block_table) {
+    if (block_size <= 0 || block_size % 64 != 0)
+      return fail(LV_ERR_UNSUPPORTED, "prefill: paged block_size %d must be a positive multiple of 64", block_size);
+    if (block_table_stride <= 0) return fail(LV_ERR_INVALID_ARGUMENT, "prefill: block_table_stride");
+    if (k_stride0 != krow || v_stride0 != krow)
+      return fail(LV_ERR_INVALID_ARGUMENT, "prefill: paged caches must be contiguous");
+  }
+  PrefillParams p;
+  p.q = static_cast<const uint16_t*>(q);
+  p.k = static_cast<const uint16_t*>(k);
+  p.v = static_cast<const uint16_t*>(v);
+  p.o = static_cast<uint16_t*>(o);
+  p.q_stride0 = q_stride0;
+  p.k_stride0 = k_stride0;
+  p.v_stride0 = v_stride0;
+  p.o_stride0 = o_stride0;
+  p.cu_q = cu_seqlens_q;
+  p.cu_k = cu_seqlens_k;
+  p.block_table = block_table;
+  p.bt_stride = block_table_stride;
+  p.block_size = block_size;
+  p.batch = batch;
+  p.max_seqlen_q = max_seqlen_q;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.scale_log2e = scale * kLog2e;
+  return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
+}
+
+int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq) {
+  return heuristic_splits(batch, num_kv_heads, max_blocks_per_seq);
+}
+
+size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num_splits) {
+  if (batch <= 0 || num_heads <= 0 || head_dim != kHeadDim || num_splits <= 1) return 0;
+  return static_cast<size_t>(batch) * num_heads * num_splits * (kHeadDim + 2) * sizeof(float);
+}
+
+int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* o,
+                   int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
+                   const int32_t* block_table, int block_table_stride, int batch,
+                   int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
+                   int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                   int num_splits, lv_stream_t stream) {
+  if (batch < 0 || max_blocks_per_seq < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_splits < 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: negative size");
+  if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "decode: head_dim %d != 128", head_dim);
+  if (num_heads % num_kv_heads != 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: num_heads %% num_kv_heads != 0");
+  if (block_size <= 0 || block_size % 32 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "decode: block_size %d must be a positive multiple of 32", block_size);
+  if (batch == 0) return LV_OK;
+  if (!q || !k_cache || !v_cache || !o || !context_lens || !block_table)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: null pointer");
+  if (block_table_stride < max_blocks_per_seq)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: block_table_stride < max_blocks_per_seq");
+  const int64_t qrow = static_cast<int64_t>(num_heads) * head_dim;
+  if (q_stride0 < qrow || o_stride0 < qrow)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: row stride smaller than num_heads*head_dim");
+  if (q_stride0 % 8 != 0 || o_stride0 % 8 != 0 || !aligned16(q) || !aligned16(o) ||
+      !aligned16(k_cache) || !aligned16(v_cache))
+    return fail(LV_ERR_UNSUPPORTED, "decode: q/o/caches must be 16-byte aligned with strides %% 8 == 0");
+  int nsplit = num_splits == 0 ? heuristic_splits(batch, num_kv_heads, max_blocks_per_seq) : num_splits;
+  if (nsplit > kMaxSplits) return fail(LV_ERR_INVALID_ARGUMENT, "decode: num_splits %d > %d", nsplit, kMaxSplits);
+  if (static_cast<int64_t>(batch) * num_kv_heads * nsplit > INT32_MAX)
+    return fail(LV_ERR_UNSUPPORTED, "decode: grid too large");
+  DecodeParams p;
+  p.q = static_cast<const uint16_t*>(q);
+  p.k_cache = static_cast<const uint16_t*>(k_cache);
+  p.v_cache = static_cast<const uint16_t*>(v_cache);
+  p.o = static_cast<uint16_t*>(o);
+  p.ws_o = nullptr;
+  p.ws_ml = nullptr;
+  if (nsplit > 1) {
+    const size_t need = lv_decode_workspace_bytes(batch, num_heads, head_dim, nsplit);
+    if (!workspace || workspace_bytes < need || !aligned16(workspace))
+      return fail(LV_ERR_WORKSPACE, "decode: workspace %zu B < %zu B needed for %d splits (or misaligned)",
+                  workspace_bytes, need, nsplit);
+    p.ws_o = static_cast<float*>(workspace);
+    p.ws_ml = p.ws_o + static_cast<size_t>(batch) * num_heads * nsplit * kHeadDim;
+  }
+  p.context_lens = context_lens;
+  p.block_table = block_table;
+  p.q_stride0 = q_stride0;
+  p.o_stride0 = o_stride0;
+  p.bt_stride = block_table_stride;
+  p.batch = batch;
+  p.block_size = block_size;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.nsplit = nsplit;
+  p.scale_log2e = scale * kLog2e;
+  return launch_decode_attn(p, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// Paged decode attention for gfx950 (MI355X): one query token per sequence attends to its
+// block_table-addressed KV cache. Semantics of the reference call
+// flash_attn_with_kvcache(q[:,None], k_cache, v_cache, cache_seqlens, block_table, causal)
+// at lightvllm/layers/attention.py:172-175.
+//
+// The op has G = num_heads/num_kv_heads FLOP per KV byte, so it is an HBM streaming problem.
+// Design:
+//   * one workgroup (4 waves) per (sequence, kv head, kv split); all G query heads of the kv
+//     head are served from one pass over K and V, so every cache byte is read exactly once;
+//   * K/V rows go HBM -> VGPR directly (no LDS round trip): 16 lanes x 16 B cover one 256-B
+//     head row, one wave instruction covers 4 consecutive tokens; U such loads for K and U for V
+//     are kept in flight per wave (software pipelined one chunk of 4U tokens ahead);
+//   * q.k partial dots use v_dot2c_f32_bf16, the 16-lane reduction uses DPP row ops;
+//   * online softmax state (m, l) per 16-lane group, merged wave -> workgroup (LDS) -> splits
+//     (fp32 workspace + a small merge kernel) with the usual (m, l) rescaling rule;
+//   * the grid depends only on static shapes (batch, kv heads, splits); each workgroup derives
+//     its token range from context_lens on device, so the launch is hipGraph-replay safe.
+#include "lv_kernels.h"
+
+namespace lv {
+
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load16(const uint16_t* p) {
+  if constexpr (NT) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  } else {
+    return *reinterpret_cast<const u32x4*>(p);
+  }
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int G, int U, bool NT>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) {
+  constexpr int TOK = 4 * U;  // tokens per wave chunk
+  const int nsplit = p.nsplit;
+  const int Hkv = p.num_kv_heads;
+  const int bid = blockIdx.x;
+  const int split = bid % nsplit;
+  const int bk = bid / nsplit;
+  const int kvh = bk % Hkv;
+  const int b = bk / Hkv;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int g = lane >> 4;  // token sub-slot inside one load instruction
+  const int i = lane & 15;  // 16-byte chunk of the 256-byte head row
+
+  const int BS = p.block_size;
+  const int ctx = p.context_lens[b];
+  const int nblk = (ctx + BS - 1) / BS;
+  const int blo = static_cast<int>(static_cast<int64_t>(split) * nblk / nsplit);
+  const int bhi = static_cast<int>(static_cast<int64_t>(split + 1) * nblk / nsplit);
+  const int t0 = blo * BS;
+  const int t1 = min(bhi * BS, ctx);
+  const int ntok = t1 - t0;
+  const int nchunks = ntok > 0 ? (ntok + TOK - 1) / TOK : 0;
+
+  const int64_t row_elems = static_cast<int64_t>(Hkv) * kHeadDim;
+  const int32_t* bt_row = p.block_table + static_cast<int64_t>(b) * p.bt_stride;
+
+  // q fragments: 8 dims of each of the G heads, kept packed as bf16 pairs.
+  u32x4 qv[G];
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    qv[h] = *reinterpret_cast<const u32x4*>(p.q + static_cast<int64_t>(b) * p.q_stride0 +
+                                            (kvh * G + h) * kHeadDim + 8 * i);
+  }
+
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int h = 0; h < G; ++h) {
+    m[h] = -INFINITY;
+    l[h] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[h][d] = 0.f;
+  }
+
+  // Element offset of (first token of chunk c, this kv head, this lane's 16-byte chunk).
+  auto chunk_base = [&](int c) -> int64_t {
+    const int t = t0 + c * TOK;
+    const int blk = bt_row[t / BS];
+    const int64_t row = static_cast<int64_t>(blk) * BS + (t % BS);
+    return (row * Hkv + kvh) * kHeadDim + 8 * i;
+  };
+  // Token offset inside chunk c for load slot u; rows past the split's end are redirected
+  // to its last valid row (their scores are masked below), so no out-of-range row is read.
+  auto tok_off = [&](int c, int u) -> int {
+    const int last = ntok - 1 - c * TOK;
+    return min(4 * u + g, last);
+  };
+
+  int c = wave;
+  if (c < nchunks) {
+    u32x4 kb[U], vb[U];
+    {
+      const int64_t base = chunk_base(c);
+#pragma unroll
+      for (int u = 0; u < U; ++u) kb[u] = load16<NT>(p.k_cache + base + tok_off(c, u) * row_elems);
+#pragma unroll
+      for (int u = 0; u < U; ++u) vb[u] = load16<NT>(p.v_cache + base + tok_off(c, u) * row_elems);
+    }
+    for (; c < nchunks; c += 4) {
+      const int cn = c + 4;
+      const bool has_next = cn < nchunks;
+      int64_t base_n = 0;
+      if (has_next) base_n = chunk_base(cn);
+
+      // ---- scores: s[u][h] = log2(e) * scale * <q_h, k_u>
+      float s[U][G];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          float d = 0.f;
+          d = dot2_bf16(kb[u][0], qv[h][0], d);
+          d = dot2_bf16(kb[u][1], qv[h][1], d);
+          d = dot2_bf16(kb[u][2], qv[h][2], d);
+          d = dot2_bf16(kb[u][3], qv[h][3], d);
+          s[u][h] = d;
+        }
+      }
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          kb[u] = load16<NT>(p.k_cache + base_n + tok_off(cn, u) * row_elems);
+      }
+      const int valid = ntok - c * TOK;  // tokens of this chunk inside the split
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = (4 * u + g) < valid;
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          const float r = row16_allreduce_sum(s[u][h]) * p.scale_log2e;
+          s[u][h] = ok ? r : -INFINITY;
+        }
+      }
+      // ---- online softmax (per 16-lane group)
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        float mx = s[0][h];
+#pragma unroll
+        for (int u = 1; u < U; ++u) mx = fmaxf(mx, s[u][h]);
+        const float m_new = fmaxf(m[h], mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m[h] - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float pe = fast_exp2(s[u][h] - m_use);
+          s[u][h] = pe;
+          psum += pe;
+        }
+        l[h] = l[h] * alpha + psum;
+        m[h] = m_new;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[h][d] *= alpha;
+      }
+      // ---- acc += p * V
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float vf[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[2 * j] = bf16_lo(vb[u][j]);
+          vf[2 * j + 1] = bf16_hi(vb[u][j]);
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) acc[h][d] = fmaf(s[u][h], vf[d], acc[h][d]);
+        }
+      }
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          vb[u] = load16<NT>(p.v_cache + base_n + tok_off(cn, u) * row_elems);
+      }
+    }
+  }
+
+  // ---- merge the 4 token groups of the wave (lanes ^16, ^32)
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      const float mo = __shfl_xor(m[h], off);
+      const float lo = __shfl_xor(l[h], off);
+      const float M = fmaxf(m[h], mo);
+      const float Mu = (M == -INFINITY) ? 0.f : M;
+      const float a = fast_exp2(m[h] - Mu);
+      const float bsc = fast_exp2(mo - Mu);
+      l[h] = l[h] * a + lo * bsc;
+      m[h] = M;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float ao = __shfl_xor(acc[h][d], off);
+        acc[h][d] = acc[h][d] * a + ao * bsc;
+      }
+    }
+  }
+
+  // ---- merge the 4 waves through LDS
+  __shared__ float sm_acc[4][G][kHeadDim];
+  __shared__ float sm_ml[4][G][2];
+  if (g == 0) {
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      float4* dst = reinterpret_cast<float4*>(&sm_acc[wave][h][8 * i]);
+      dst[0] = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+      dst[1] = make_float4(acc[h][4], acc[h][5], acc[h][6], acc[h][7]);
+      if (i == 0) {
+        sm_ml[wave][h][0] = m[h];
+        sm_ml[wave][h][1] = l[h];
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int e = tid; e < G * kHeadDim; e += 256) {
+    const int h = e / kHeadDim;
+    const int d = e % kHeadDim;
+    float M = sm_ml[0][h][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_ml[w][h][0]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float val = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = fast_exp2(sm_ml[w][h][0] - Mu);
+      val += sc * sm_acc[w][h][d];
+      L += sc * sm_ml[w][h][1];
+    }
+    const int hq = kvh * G + h;
+    if (nsplit == 1) {
+      const float r = L > 0.f ? val / L : 0.f;
+      p.o[static_cast<int64_t>(b) * p.o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
+    } else {
+      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * nsplit + split;
+      p.ws_o[slot * kHeadDim + d] = val;
+      if (d == 0) {
+        p.ws_ml[slot * 2 + 0] = M;
+        p.ws_ml[slot * 2 + 1] = L;
+      }
+    }
+  }
+}
+
+// Combine the nsplit partial results of one (sequence, query head): one block of 128 lanes.
+__global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restrict__ ws_o,
+                                                           const float* __restrict__ ws_ml,
+                                                           uint16_t* __restrict__ o,
+                                                           int64_t o_stride0, int num_heads,
+                                                           int nsplit) {
+  const int bh = blockIdx.x;
+  const int b = bh / num_heads;
+  const int hq = bh % num_heads;
+  const int d = threadIdx.x;
+  const int64_t base = static_cast<int64_t>(bh) * nsplit;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(base + s) * 2]);
+  const float Mu = (M == -INFINITY) ? 0.f : M;
+  float val = 0.f, L = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float sc = fast_exp2(ws_ml[(base + s) * 2] - Mu);
+    val += sc * ws_o[(base + s) * kHeadDim + d];
+    L += sc * ws_ml[(base + s) * 2 + 1];
+  }
+  const float r = L > 0.f ? val / L : 0.f;
+  o[static_cast<int64_t>(b) * o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
+}
+
+template <int G, int U>
+static void launch_g(const DecodeParams& p, hipStream_t stream) {
+  const unsigned grid = static_cast<unsigned>(p.batch) * p.num_kv_heads * p.nsplit;
+  hipLaunchKernelGGL((decode_attn_kernel<G, U, true>), dim3(grid), dim3(256), 0, stream, p);
+}
+
+int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
+  const int G = p.num_heads / p.num_kv_heads;
+  switch (G) {
+    case 1: launch_g<1, 8>(p, stream); break;
+    case 2: launch_g<2, 8>(p, stream); break;
+    case 4: launch_g<4, 4>(p, stream); break;
+    case 8: launch_g<8, 4>(p, stream); break;
+    default:
+      return fail(LV_ERR_UNSUPPORTED, "decode: num_heads/num_kv_heads = %d not in {1,2,4,8}", G);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_attn launch: %s", hipGetErrorString(e));
+  if (p.nsplit > 1) {
+    hipLaunchKernelGGL(decode_merge_kernel, dim3(static_cast<unsigned>(p.batch) * p.num_heads),
+                       dim3(128), 0, stream, p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads,
+                       p.nsplit);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_merge launch: %s", hipGetErrorString(e));
+  }
+  return LV_OK;
+}
+
+}  // namespace lv

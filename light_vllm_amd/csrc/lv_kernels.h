@@ -1,0 +1,42 @@
+// Launcher interfaces between the C-ABI layer (api.hip) and the kernel translation units.
+#pragma once
+
+#include "lv_common.h"
+
+namespace lv {
+
+struct DecodeParams {
+  const uint16_t* q;
+  const uint16_t* k_cache;
+  const uint16_t* v_cache;
+  uint16_t* o;
+  float* ws_o;   // [batch, Hq, nsplit, 128] unnormalised partial outputs
+  float* ws_ml;  // [batch, Hq, nsplit, 2]   (running max in log2 units, sum)
+  const int32_t* context_lens;
+  const int32_t* block_table;
+  int64_t q_stride0, o_stride0;
+  int bt_stride, batch, block_size, num_heads, num_kv_heads, nsplit;
+  float scale_log2e;
+};
+
+struct PrefillParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* o;
+  int64_t q_stride0, k_stride0, v_stride0, o_stride0;
+  const int32_t* cu_q;
+  const int32_t* cu_k;
+  const int32_t* block_table;  // nullptr = packed K/V
+  int bt_stride, block_size, batch, max_seqlen_q, num_heads, num_kv_heads;
+  float scale_log2e;
+};
+
+int launch_store_kvcache(const void* key, const void* value, int64_t key_stride0,
+                         int64_t value_stride0, void* k_cache, void* v_cache,
+                         const int32_t* slot_mapping, int64_t num_tokens, int row_elems,
+                         int64_t num_slots, hipStream_t stream);
+int launch_decode_attn(const DecodeParams& p, hipStream_t stream);
+int launch_prefill_attn(const PrefillParams& p, hipStream_t stream);
+
+}  // namespace lv

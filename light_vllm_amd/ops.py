@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI (include/lv_attention.h): shape/dtype checks that mirror
+the reference's asserts (lightvllm/layers/attention.py:94-97), raw pointers + torch's current
+stream passed down. All work is stream-ordered; nothing here synchronises."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_BF16 = torch.bfloat16
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_gpu(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("light_vllm_amd ops run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback")
+        if t.device != dev:
+            raise RuntimeError("all tensors must live on the same device")
+    return dev
+
+
+def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
+                  v_cache: torch.Tensor, slot_mapping: torch.Tensor) -> None:
+    """k_cache.view(-1, Hkv*D)[slot_mapping[i]] = key[i]; same for value. Slots < 0 are skipped.
+
+    key/value: [N, Hkv, D] bf16, last two dims contiguous, row stride free.
+    k_cache/v_cache: [num_blocks, block_size, Hkv, D] contiguous. slot_mapping: int32 [N].
+    """
+    dev = _require_gpu(key, value, k_cache, v_cache, slot_mapping)
+    N, num_heads, head_dim = key.shape
+    D = num_heads * head_dim
+    assert value.shape == key.shape
+    assert key.dtype == _BF16 and value.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16
+    assert key.stride(-1) == 1 and value.stride(-1) == 1
+    assert key.stride(1) == head_dim and value.stride(1) == head_dim
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert k_cache.shape == v_cache.shape and k_cache.numel() % D == 0
+    assert slot_mapping.dtype == torch.int32 and slot_mapping.is_contiguous()
+    assert slot_mapping.numel() == N
+    if N == 0:
+        return
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.lv_store_kvcache(key.data_ptr(), value.data_ptr(), key.stride(0), value.stride(0),
+                                  k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(),
+                                  N, num_heads, head_dim, k_cache.numel() // D, _stream_ptr(dev))
+    _lib.check(rc, "lv_store_kvcache")
+
+
+def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                      cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
+                      max_seqlen_q: int, max_seqlen_k: int, softmax_scale: float,
+                      block_table: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Varlen causal attention (bottom-right aligned mask), GQA, optional paged K/V.
+
+    q: [total_q, Hq, D]. Packed mode: k/v [total_k, Hkv, D]. Paged mode (block_table given):
+    k/v are the caches [num_blocks, block_size, Hkv, D] and block_table is int32 [B, max_blocks].
+    """
+    dev = _require_gpu(q, k, v, cu_seqlens_q, cu_seqlens_k)
+    total_q, Hq, D = q.shape
+    assert q.dtype == _BF16 and k.dtype == _BF16 and v.dtype == _BF16
+    assert q.stride(-1) == 1 and q.stride(1) == D
+    assert cu_seqlens_q.dtype == torch.int32 and cu_seqlens_k.dtype == torch.int32
+    assert cu_seqlens_q.is_contiguous() and cu_seqlens_k.is_contiguous()
+    B = cu_seqlens_q.numel() - 1
+    assert cu_seqlens_k.numel() == B + 1
+    if block_table is not None:
+        _require_gpu(q, block_table)
+        assert k.dim() == 4 and v.shape == k.shape and k.is_contiguous() and v.is_contiguous()
+        assert block_table.dtype == torch.int32 and block_table.dim() == 2 and block_table.stride(1) == 1
+        assert block_table.size(0) == B
+        block_size, Hkv = k.size(1), k.size(2)
+        assert k.size(3) == D
+        k_stride0 = v_stride0 = Hkv * D
+        bt_ptr, bt_stride = block_table.data_ptr(), block_table.stride(0)
+    else:
+        assert k.dim() == 3 and v.shape == k.shape
+        Hkv = k.size(1)
+        assert k.size(2) == D
+        assert k.stride(-1) == 1 and v.stride(-1) == 1 and k.stride(1) == D and v.stride(1) == D
+        k_stride0, v_stride0 = k.stride(0), v.stride(0)
+        block_size, bt_ptr, bt_stride = 0, None, 0
+    if out is None:
+        out = torch.empty((total_q, Hq, D), dtype=_BF16, device=dev)
+    else:
+        assert out.shape == (total_q, Hq, D) and out.dtype == _BF16 and out.stride(-1) == 1 and out.stride(1) == D
+    if total_q == 0 or B == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                 q.stride(0), k_stride0, v_stride0, out.stride(0),
+                                 cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), B,
+                                 int(max_seqlen_q), int(max_seqlen_k), bt_ptr, bt_stride, block_size,
+                                 Hq, Hkv, D, float(softmax_scale), _stream_ptr(dev))
+    _lib.check(rc, "lv_prefill_attn")
+    return out
+
+
+# One split-KV workspace per device, shared by all layers (launches are stream-ordered and each
+# decode call finishes reading it in its own merge kernel before the next layer writes it).
+_WORKSPACE: Dict[int, torch.Tensor] = {}
+
+
+def decode_num_splits(batch: int, num_kv_heads: int, max_blocks_per_seq: int) -> int:
+    return _lib.load().lv_decode_num_splits(batch, num_kv_heads, max_blocks_per_seq)
+
+
+def decode_workspace_bytes(batch: int, num_heads: int, head_dim: int, num_splits: int) -> int:
+    return _lib.load().lv_decode_workspace_bytes(batch, num_heads, head_dim, num_splits)
+
+
+def reserve_decode_workspace(device: torch.device, nbytes: int) -> None:
+    """Grow the cached workspace of `device` to at least nbytes. Call before hipGraph capture
+    with the largest (batch, splits) the graphs will see, so capture never has to allocate."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    cur = _WORKSPACE.get(idx)
+    if cur is None or cur.numel() < nbytes:
+        _WORKSPACE[idx] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{idx}")
+
+
+def _workspace(device: torch.device, nbytes: int) -> Tuple[Optional[int], int, Optional[torch.Tensor]]:
+    if nbytes == 0:
+        return None, 0, None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = _WORKSPACE.get(idx)
+    if cur is None or cur.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # served from the capturing graph's private pool; lives as long as the graph does
+            tmp = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            return tmp.data_ptr(), nbytes, tmp
+        reserve_decode_workspace(device, nbytes)
+        cur = _WORKSPACE[idx]
+    return cur.data_ptr(), cur.numel(), cur
+
+
+def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                     context_lens: torch.Tensor, block_table: torch.Tensor, softmax_scale: float,
+                     num_splits: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One query token per sequence over the paged cache.
+
+    q: [B, Hq, D]; caches [num_blocks, block_size, Hkv, D] contiguous; context_lens int32 [B]
+    (already counting the token stored this step); block_table int32 [B, max_blocks].
+    num_splits: 0 = library heuristic, 1 = single pass, n = split-KV + merge.
+    """
+    dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
+    B, Hq, D = q.shape
+    assert q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16
+    assert q.stride(-1) == 1 and q.stride(1) == D
+    assert k_cache.dim() == 4 and k_cache.shape == v_cache.shape
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    block_size, Hkv = k_cache.size(1), k_cache.size(2)
+    assert k_cache.size(3) == D
+    assert context_lens.dtype == torch.int32 and context_lens.is_contiguous() and context_lens.numel() == B
+    assert block_table.dtype == torch.int32 and block_table.dim() == 2 and block_table.stride(1) == 1
+    assert block_table.size(0) == B
+    max_blocks = block_table.size(1)
+    if out is None:
+        out = torch.empty((B, Hq, D), dtype=_BF16, device=dev)
+    else:
+        assert out.shape == (B, Hq, D) and out.dtype == _BF16 and out.stride(-1) == 1 and out.stride(1) == D
+    if B == 0:
+        return out
+    lib = _lib.load()
+    nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks)
+    ws_ptr, ws_bytes, keep = _workspace(dev, lib.lv_decode_workspace_bytes(B, Hq, D, nsplit))
+    with torch.cuda.device(dev):
+        rc = lib.lv_decode_attn(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                                q.stride(0), out.stride(0), context_lens.data_ptr(),
+                                block_table.data_ptr(), block_table.stride(0), B, max_blocks, block_size,
+                                Hq, Hkv, D, float(softmax_scale), ws_ptr, ws_bytes, nsplit,
+                                _stream_ptr(dev))
+    _lib.check(rc, "lv_decode_attn")
+    del keep
+    return out

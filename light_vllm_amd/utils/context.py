@@ -1,0 +1,44 @@
+"""Per-step metadata bus between the model runner and the attention / LM-head layers.
+
+Same contract as the reference's lightvllm/utils/context.py:15-75: a module-global dataclass that
+`set_context` replaces wholesale before each forward pass and `reset_context` clears after it.
+Field order and defaults match so positional `set_context(...)` calls behave identically.
+Not thread-safe, by design of the contract (one Python thread per rank process).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class Context:
+    is_prefill: bool = False
+    cu_seqlens_q: Optional[torch.Tensor] = None   # int32 [B+1], prefill only
+    cu_seqlens_k: Optional[torch.Tensor] = None   # int32 [B+1], prefill only
+    max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    slot_mapping: Optional[torch.Tensor] = None   # int32 [N]
+    context_lens: Optional[torch.Tensor] = None   # int32 [B], decode only
+    block_tables: Optional[torch.Tensor] = None   # int32 [B, max_blocks], -1 padded
+
+
+_CONTEXT = Context()
+
+
+def get_context() -> Context:
+    return _CONTEXT
+
+
+def set_context(is_prefill, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0, max_seqlen_k=0,
+                slot_mapping=None, context_lens=None, block_tables=None) -> None:
+    global _CONTEXT
+    _CONTEXT = Context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                       slot_mapping, context_lens, block_tables)
+
+
+def reset_context() -> None:
+    global _CONTEXT
+    _CONTEXT = Context()
