@@ -1,0 +1,106 @@
+"""Kernel-level sweep on one MI355X: achieved algorithmic GB/s (decode, store) or TFLOP/s (prefill)
+per shape, timed with events on torch's current stream. Not the contract bench (see bench.py)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from light_vllm_amd import ops  # noqa: E402
+
+D, BLOCK = 128, 256
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False):
+    bps = (ctx + BLOCK - 1) // BLOCK
+    nblk = B * bps
+    # several distinct caches so the working set exceeds the 256 MiB Infinity Cache
+    per_layer = 2 * nblk * BLOCK * Hkv * D * 2
+    layers = max(layers, min(64, (1 << 30) // max(per_layer, 1) + 1))
+    kv = torch.empty(layers, 2, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev).normal_()
+    q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
+    bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
+    if ragged:
+        lens = torch.randint(1, ctx + 1, (B,), dtype=torch.int32)
+    else:
+        lens = torch.full((B,), ctx, dtype=torch.int32)
+    ctx_t = lens.to(dev)
+    out = torch.empty_like(q)
+    state = {"i": 0}
+
+    def fn():
+        l = state["i"] % layers
+        state["i"] += 1
+        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out)
+
+    t = timeit(fn)
+    tot = int(lens.sum())
+    nb = int(((lens + BLOCK - 1) // BLOCK).sum())
+    bytes_ = tot * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nb
+    ns = nsplit or ops.decode_num_splits(B, Hkv, bps)
+    return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, us=round(t * 1e6, 1),
+                GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
+
+
+def prefill_case(lens, Hq, Hkv, paged_prefix=0):
+    total = sum(lens)
+    q = torch.randn(total, Hq, D, device=dev).to(torch.bfloat16)
+    k = torch.randn(total, Hkv, D, device=dev).to(torch.bfloat16)
+    v = torch.randn(total, Hkv, D, device=dev).to(torch.bfloat16)
+    cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+
+    def fn():
+        ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out)
+
+    t = timeit(fn, iters=10, warmup=2)
+    flops = sum(4 * Hq * D * (L * L - L * (L - 1) // 2) for L in lens)
+    return dict(kind="prefill", lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
+                ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="decode")
+    args = ap.parse_args()
+    rows = []
+    if args.what in ("decode", "all"):
+        for (Hq, Hkv) in [(16, 8), (32, 8), (64, 8)]:
+            rows.append(decode_case(256, 1024, Hq, Hkv))
+        rows.append(decode_case(256, 1024, 32, 8, ragged=True))
+        rows.append(decode_case(64, 4096, 32, 8))
+        for (Hq, Hkv) in [(16, 4), (8, 2), (4, 1), (8, 1)]:
+            for B in (1, 8, 64):
+                rows.append(decode_case(B, 32768, Hq, Hkv))
+        rows.append(decode_case(1, 32768, 32, 8))
+        rows.append(decode_case(8, 1024, 32, 8))
+        rows.append(decode_case(1, 1024, 32, 8))
+    if args.what in ("prefill", "all"):
+        rows.append(prefill_case([4096] * 4, 32, 8))
+        rows.append(prefill_case([4096, 3000, 1024, 8264], 32, 8))
+        rows.append(prefill_case([1024] * 16, 16, 8))
+        rows.append(prefill_case([4096] * 4, 8, 1))
+    for r in rows:
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
