@@ -1,0 +1,112 @@
+"""Varlen causal prefill parity: HIP MFMA kernel vs the CPU fp32 oracle (max-abs <= 2e-2)."""
+import pytest
+import torch
+
+from oracle.attention_oracle import prefill_ref
+from tests._cases import make_prefill_case, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def _run(gpu, case):
+    from light_vllm_amd import ops
+    d = to_dev(case, gpu)
+    out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"],
+                                d["scale"], block_table=d["block_table"])
+    torch.cuda.synchronize()
+    return out
+
+
+def _check(gpu, case):
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"],
+                      case["block_table"])
+    out = _run(gpu, case)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= TOL, f"max-abs {err}"
+    return out
+
+
+HEADS = [(16, 8), (32, 8), (4, 1), (8, 1)]
+
+
+@pytest.mark.parametrize("Hq,Hkv", HEADS)
+def test_prefill_packed_ragged(gpu, Hq, Hkv):
+    lens = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 700]
+    _check(gpu, make_prefill_case(21, lens, lens, Hq, Hkv))
+
+
+def test_prefill_single_long(gpu):
+    _check(gpu, make_prefill_case(22, [1500], [1500], 16, 8))
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (8, 1)])
+def test_prefill_paged_prefix(gpu, Hq, Hkv):
+    """Prefix-cached prefill: Lq = len - cached, Lk = len, K/V read through the block table."""
+    lens_k = [600, 256 + 17, 1024, 300]
+    cached = [256, 256, 768, 0]
+    lens_q = [k - c for k, c in zip(lens_k, cached)]
+    _check(gpu, make_prefill_case(23, lens_q, lens_k, Hq, Hkv, paged=True))
+
+
+def test_prefill_paged_block64(gpu):
+    _check(gpu, make_prefill_case(24, [100, 7], [228, 71], 16, 8, block_size=64, paged=True))
+
+
+def test_prefill_strided_inputs(gpu):
+    """q/k/v as views into a fused qkv activation (row stride (Hq+2Hkv)*D), as models/qwen3.py:95."""
+    from light_vllm_amd import ops
+    Hq, Hkv, D = 16, 8, 128
+    case = make_prefill_case(25, [130, 64], [130, 64], Hq, Hkv)
+    N = case["q"].size(0)
+    qkv = torch.empty(N, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16)
+    qkv[:, :Hq * D] = case["q"].view(N, -1)
+    qkv[:, Hq * D:(Hq + Hkv) * D] = case["k"].view(N, -1)
+    qkv[:, (Hq + Hkv) * D:] = case["v"].view(N, -1)
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"])
+    g = qkv.to(gpu)
+    q, k, v = g.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    out = ops.prefill_attention(q.view(N, Hq, D), k.view(N, Hkv, D), v.view(N, Hkv, D),
+                                case["cu_q"].to(gpu), case["cu_k"].to(gpu), 130, 130, case["scale"])
+    torch.cuda.synchronize()
+    assert (out.float().cpu() - ref).abs().max().item() <= TOL
+
+
+def test_prefill_spiked_scores(gpu):
+    """Forces the running-max rescale: a late key aligned with one query row, far above the rest."""
+    case = make_prefill_case(26, [512], [512], 16, 8)
+    case["k"][400, 0] = (case["q"][450, 1].float() * 4.0).to(torch.bfloat16)
+    case["k"][70, 3] = (case["q"][300, 6].float() * 4.0).to(torch.bfloat16)
+    _check(gpu, case)
+
+
+def test_prefill_config3_shape_sampled(gpu):
+    """BASELINE config 3 (Qwen3-8B, 4x4096 packed) at full size: row blocks sampled against the
+    oracle (a causal row block r0..r1 of a sequence only depends on keys 0..r1)."""
+    Hq, Hkv, L = 32, 8, 4096
+    case = make_prefill_case(27, [L] * 4, [L] * 4, Hq, Hkv)
+    out = _run(gpu, case).float().cpu()
+    for b, r0, r1 in [(0, 0, 40), (1, 2000, 2040), (3, 4056, 4096), (2, 120, 136)]:
+        s = b * L
+        q = case["q"][s + r0:s + r1]
+        k = case["k"][s:s + r1]
+        v = case["v"][s:s + r1]
+        cu_q = torch.tensor([0, r1 - r0], dtype=torch.int32)
+        cu_k = torch.tensor([0, r1], dtype=torch.int32)
+        ref = prefill_ref(q, k, v, cu_q, cu_k, case["scale"])
+        err = (out[s + r0:s + r1] - ref).abs().max().item()
+        assert err <= TOL, f"seq {b} rows {r0}:{r1} max-abs {err}"
+
+
+def test_prefill_matches_decode_last_row(gpu):
+    """Size-independent property: the last prefill row of a sequence equals decode over its cache."""
+    from light_vllm_amd import ops
+    Hq, Hkv, D, L = 32, 8, 128, 777
+    case = make_prefill_case(28, [L - 512], [L], Hq, Hkv, paged=True)
+    d = to_dev(case, gpu)
+    out = _run(gpu, case)
+    q_last = d["q"][-1:].contiguous()
+    dec = ops.decode_attention(q_last, d["k"], d["v"], torch.tensor([L], dtype=torch.int32, device=gpu),
+                               d["block_table"], d["scale"])
+    torch.cuda.synchronize()
+    assert (out[-1:].float() - dec.float()).abs().max().item() <= 1e-2
