@@ -1,0 +1,319 @@
+"""Per-GPU worker: owns the model shard, the paged KV tensor and the per-step Context.
+
+Same responsibilities and step protocol as the reference's ModelRunner
+(lightvllm/engine/model_runner.py:17-548); the parts the attention path depends on are re-done for
+MI355X:
+
+  * prepare_prefill / prepare_decode / prepare_block_tables build exactly the reference's tensors
+    (:256-418) — input_ids, positions (decode uses position len(seq), :405), cu_seqlens_q/k,
+    slot_mapping, context_lens, -1 padded block tables — through one pinned staging buffer and
+    asynchronous H2D copies;
+  * allocate_kv_cache sizes the cache from free HBM with the reference's formula (:216-236) in
+    64-bit arithmetic (a 288 GB device holds > 2^31 elements per layer) and binds
+    kv_cache[0, i] / kv_cache[1, i] to every module that has k_cache and v_cache (:249-254);
+  * decode runs from hipGraphs captured per batch-size bucket (:489-548). Padding rows of a bucket
+    carry slot -1, which lv_store_kvcache skips, and context_len 0, which lv_decode_attn turns
+    into a zero row. (The reference pads with slot 0 and so overwrites cache slot 0 on every
+    padded replay, :448-455.) The split-KV workspace is reserved before capture.
+"""
+from __future__ import annotations
+
+import pickle
+from multiprocessing.shared_memory import SharedMemory
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..config import Config
+from ..layers.sampler import Sampler
+from ..models.qwen3 import Qwen3ForCausalLM
+from ..utils.context import get_context, reset_context, set_context
+from ..utils.loader import load_model, load_random
+from .sequence import Sequence
+
+_SHM_NAME = "lightvllm_amd"
+
+
+class ModelRunner:
+
+    def __init__(self, config: Config, rank: int, event):
+        self.config = config
+        hf_config = config.hf_config
+        self.block_size = config.kvcache_block_size
+        Sequence.set_block_size(self.block_size)
+        self.enforce_eager = config.enforce_eager
+        self.world_size = config.tensor_parallel_size
+        self.rank = rank
+        self.event = event
+        self.on_gpu = config.device != "cpu"
+
+        if self.on_gpu:
+            self.device = torch.device(f"cuda:{rank}")
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device("cpu")
+        self._own_group = False
+        if self.world_size > 1 and not dist.is_initialized():
+            backend = "nccl" if self.on_gpu else "gloo"   # "nccl" is RCCL on ROCm
+            kwargs = {"device_id": self.device} if self.on_gpu else {}
+            dist.init_process_group(backend, config.dist_init_method, world_size=self.world_size,
+                                    rank=rank, **kwargs)
+            self._own_group = True
+
+        default_dtype = torch.get_default_dtype()
+        dtype = getattr(hf_config, "torch_dtype", None) or getattr(hf_config, "dtype", None) or torch.bfloat16
+        self.dtype = dtype
+        torch.set_default_dtype(dtype)
+        torch.set_default_device(self.device)
+        try:
+            self.model = Qwen3ForCausalLM(hf_config)
+            if config.random_seed is not None:
+                load_random(self.model, hf_config, config.random_seed)
+            else:
+                load_model(self.model, config.model)
+            self.sampler = Sampler()
+            self.kv_cache = None
+            self.warmup_model()
+            self.allocate_kv_cache()
+            if not self.enforce_eager:
+                self.capture_graphs()
+        finally:
+            torch.set_default_device("cpu")
+            torch.set_default_dtype(default_dtype)
+
+        if self.world_size > 1:
+            if rank == 0:
+                self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
+                dist.barrier()
+            else:
+                dist.barrier()
+                self.shm = SharedMemory(name=_SHM_NAME)
+                self.loop()
+
+    # ------------------------------------------------------------------ lifecycle / step RPC
+    def exit(self):
+        if self.world_size > 1:
+            self.shm.close()
+            dist.barrier()
+            if self.rank == 0:
+                self.shm.unlink()
+        if not self.enforce_eager:
+            del self.graphs, self.graph_pool
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        if self._own_group:
+            dist.destroy_process_group()
+
+    def loop(self):
+        while True:
+            method_name, args = self.read_shm()
+            self.call(method_name, *args)
+            if method_name == "exit":
+                break
+
+    def read_shm(self):
+        assert self.world_size > 1 and self.rank > 0
+        self.event.wait()
+        n = int.from_bytes(self.shm.buf[0:4], "little")
+        method_name, *args = pickle.loads(self.shm.buf[4:n + 4])
+        self.event.clear()
+        return method_name, args
+
+    def write_shm(self, method_name, *args):
+        assert self.world_size > 1 and self.rank == 0
+        data = pickle.dumps([method_name, *args])
+        n = len(data)
+        assert n + 4 <= self.shm.size, "step message exceeds the shared-memory segment"
+        self.shm.buf[0:4] = n.to_bytes(4, "little")
+        self.shm.buf[4:n + 4] = data
+        for event in self.event:
+            event.set()
+
+    def call(self, method_name, *args):
+        if self.world_size > 1 and self.rank == 0:
+            self.write_shm(method_name, *args)
+        method = getattr(self, method_name, None)
+        if method:
+            return method(*args)
+
+    # ------------------------------------------------------------------ memory
+    def warmup_model(self):
+        """One prefill of the largest batch with empty caches (Attention skips the store),
+        so the peak activation footprint is known before the KV cache is sized."""
+        if self.on_gpu:
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+        cfg = self.config
+        num_seqs = min(cfg.max_num_batched_tokens // cfg.max_model_len, cfg.max_num_seqs)
+        seqs = [Sequence([0] * cfg.max_model_len) for _ in range(num_seqs)]
+        self.run(seqs, True)
+        if self.on_gpu:
+            torch.cuda.empty_cache()
+
+    def kv_block_bytes(self) -> int:
+        hf = self.config.hf_config
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        itemsize = torch.empty((), dtype=self.dtype).element_size()
+        return 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * head_dim * itemsize
+
+    def allocate_kv_cache(self):
+        cfg = self.config
+        hf = cfg.hf_config
+        block_bytes = self.kv_block_bytes()
+        if self.on_gpu:
+            free, total = torch.cuda.mem_get_info()
+            used = total - free
+            stats = torch.cuda.memory_stats()
+            peak = stats["allocated_bytes.all.peak"]
+            current = stats["allocated_bytes.all.current"]
+            available = int(total * cfg.gpu_memory_utilization) - used - peak + current
+            num_blocks = available // block_bytes
+            if cfg.num_kvcache_blocks > 0:
+                num_blocks = min(num_blocks, cfg.num_kvcache_blocks)
+        else:
+            assert cfg.num_kvcache_blocks > 0, "CPU plumbing runs need an explicit num_kvcache_blocks"
+            num_blocks = cfg.num_kvcache_blocks
+        assert num_blocks > 0, "not enough memory for the KV cache"
+        cfg.num_kvcache_blocks = int(num_blocks)
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        self.kv_cache = torch.zeros(2, hf.num_hidden_layers, cfg.num_kvcache_blocks, self.block_size,
+                                    num_kv_heads, head_dim, dtype=self.dtype, device=self.device)
+        layer_id = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = self.kv_cache[0, layer_id]
+                module.v_cache = self.kv_cache[1, layer_id]
+                layer_id += 1
+        assert layer_id == hf.num_hidden_layers
+
+    # ------------------------------------------------------------------ step inputs
+    def _to_device(self, values, dtype) -> torch.Tensor:
+        if self.on_gpu:
+            return torch.tensor(values, dtype=dtype, pin_memory=True).cuda(self.device, non_blocking=True)
+        return torch.tensor(values, dtype=dtype)
+
+    def prepare_block_tables(self, seqs: list[Sequence]) -> torch.Tensor:
+        width = max(len(seq.block_table) for seq in seqs)
+        rows = [seq.block_table + [-1] * (width - len(seq.block_table)) for seq in seqs]
+        return self._to_device(rows, torch.int32)
+
+    def prepare_prefill(self, seqs: list[Sequence]):
+        input_ids, positions, slot_mapping = [], [], []
+        cu_q, cu_k = [0], [0]
+        max_q = max_k = 0
+        bs = self.block_size
+        for seq in seqs:
+            n = len(seq)
+            cached = seq.num_cached_tokens
+            input_ids.extend(seq[cached:])
+            positions.extend(range(cached, n))
+            lq, lk = n - cached, n
+            cu_q.append(cu_q[-1] + lq)
+            cu_k.append(cu_k[-1] + lk)
+            max_q, max_k = max(max_q, lq), max(max_k, lk)
+            if not seq.block_table:      # warmup: nothing to store
+                continue
+            last = seq.num_blocks - 1
+            for i in range(seq.num_cached_blocks, seq.num_blocks):
+                start = seq.block_table[i] * bs
+                count = bs if i != last else seq.last_block_num_tokens
+                slot_mapping.extend(range(start, start + count))
+        block_tables = self.prepare_block_tables(seqs) if cu_k[-1] > cu_q[-1] else None
+        input_ids = self._to_device(input_ids, torch.int64)
+        positions = self._to_device(positions, torch.int64)
+        cu_q_t = self._to_device(cu_q, torch.int32)
+        cu_k_t = self._to_device(cu_k, torch.int32)
+        slot_mapping = self._to_device(slot_mapping, torch.int32)
+        set_context(True, cu_q_t, cu_k_t, max_q, max_k, slot_mapping, None, block_tables)
+        return input_ids, positions
+
+    def prepare_decode(self, seqs: list[Sequence]):
+        bs = self.block_size
+        input_ids = [seq.last_token for seq in seqs]
+        positions = [len(seq) for seq in seqs]
+        context_lens = [len(seq) for seq in seqs]
+        slot_mapping = [seq.block_table[-1] * bs + seq.last_block_num_tokens - 1 for seq in seqs]
+        input_ids = self._to_device(input_ids, torch.int64)
+        positions = self._to_device(positions, torch.int64)
+        slot_mapping = self._to_device(slot_mapping, torch.int32)
+        context_lens = self._to_device(context_lens, torch.int32)
+        block_tables = self.prepare_block_tables(seqs)
+        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
+        return input_ids, positions
+
+    def prepare_sample(self, seqs: list[Sequence]) -> torch.Tensor:
+        return self._to_device([seq.temperature for seq in seqs], torch.float32)
+
+    # ------------------------------------------------------------------ forward
+    @torch.inference_mode()
+    def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool):
+        if is_prefill or self.enforce_eager or input_ids.size(0) > self.graph_bs[-1]:
+            return self.model.compute_logits(self.model(input_ids, positions))
+        bs = input_ids.size(0)
+        context = get_context()
+        bucket = next(x for x in self.graph_bs if x >= bs)
+        gv = self.graph_vars
+        gv["input_ids"].zero_()
+        gv["positions"].zero_()
+        gv["slot_mapping"].fill_(-1)      # padding rows store nothing
+        gv["context_lens"].zero_()        # ... and attend to nothing
+        gv["block_tables"].zero_()
+        gv["input_ids"][:bs] = input_ids
+        gv["positions"][:bs] = positions
+        gv["slot_mapping"][:bs] = context.slot_mapping
+        gv["context_lens"][:bs] = context.context_lens
+        gv["block_tables"][:bs, :context.block_tables.size(1)] = context.block_tables
+        self.graphs[bucket].replay()
+        return self.model.compute_logits(gv["outputs"][:bs])
+
+    def run(self, seqs: list[Sequence], is_prefill: bool):
+        input_ids, positions = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
+        temperatures = self.prepare_sample(seqs) if self.rank == 0 else None
+        logits = self.run_model(input_ids, positions, is_prefill)
+        token_ids = self.sampler(logits, temperatures).tolist() if self.rank == 0 else None
+        reset_context()
+        return token_ids
+
+    @torch.inference_mode()
+    def capture_graphs(self):
+        """hipGraph capture of the decode forward pass for batch buckets 1, 2, 4, 8, 16, 32, ...
+        Largest first so smaller graphs reuse its memory pool."""
+        assert self.on_gpu
+        cfg, hf = self.config, self.config.hf_config
+        max_bs = min(cfg.max_num_seqs, 512)
+        max_num_blocks = -(-cfg.max_model_len // self.block_size)
+        dev = self.device
+        input_ids = torch.zeros(max_bs, dtype=torch.int64, device=dev)
+        positions = torch.zeros(max_bs, dtype=torch.int64, device=dev)
+        slot_mapping = torch.full((max_bs,), -1, dtype=torch.int32, device=dev)
+        context_lens = torch.zeros(max_bs, dtype=torch.int32, device=dev)
+        block_tables = torch.zeros(max_bs, max_num_blocks, dtype=torch.int32, device=dev)
+        outputs = torch.zeros(max_bs, hf.hidden_size, dtype=self.dtype, device=dev)
+        self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+        self.graphs = {}
+        self.graph_pool = None
+
+        hq = hf.num_attention_heads // self.world_size
+        hkv = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks))
+                   for b in self.graph_bs)
+        ops.reserve_decode_workspace(dev, need)
+
+        for bs in reversed(self.graph_bs):
+            graph = torch.cuda.CUDAGraph()
+            set_context(False, slot_mapping=slot_mapping[:bs], context_lens=context_lens[:bs],
+                        block_tables=block_tables[:bs])
+            outputs[:bs] = self.model(input_ids[:bs], positions[:bs])   # warm run outside capture
+            with torch.cuda.graph(graph, pool=self.graph_pool):
+                outputs[:bs] = self.model(input_ids[:bs], positions[:bs])
+            if self.graph_pool is None:
+                self.graph_pool = graph.pool()
+            self.graphs[bs] = graph
+            torch.cuda.synchronize()
+            reset_context()
+        self.graph_vars = dict(input_ids=input_ids, positions=positions, slot_mapping=slot_mapping,
+                               context_lens=context_lens, block_tables=block_tables, outputs=outputs)

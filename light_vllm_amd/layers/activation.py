@@ -1,0 +1,12 @@
+"""SwiGLU: silu(gate) * up over the two halves of the last dim (reference "native" backend,
+lightvllm/layers/activation.py:7-29)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class SiluAndMul(nn.Module):
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        gate, up = torch.chunk(x, 2, dim=-1)
+        return F.silu(gate) * up

@@ -1,0 +1,16 @@
+"""Greedy for temperature 0, exponential-race (Gumbel-max) sampling otherwise
+(reference: lightvllm/layers/sampler.py:16-64)."""
+import torch
+from torch import nn
+
+
+class Sampler(nn.Module):
+
+    def forward(self, logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+        logits = logits.to(torch.float)
+        greedy = logits.argmax(-1)
+        logits = logits / temperatures.unsqueeze(1)
+        probs = torch.softmax(logits, -1, dtype=torch.float)
+        noise = torch.empty_like(probs).exponential_(1) + 1e-10
+        sampled = (probs / noise).argmax(-1)
+        return torch.where(temperatures == 0, greedy, sampled)

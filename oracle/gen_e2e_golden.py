@@ -1,0 +1,182 @@
+"""Writes tests/golden/e2e_config1.json: greedy decoding of BASELINE config 1 (Qwen3-0.6B shapes,
+random-init, 4 x 256-token prompts, 64 greedy steps) by the REFERENCE's own model stack on CPU.
+
+What runs from /root/reference: Qwen3ForCausalLM, the Attention.forward dispatcher, the TP layers,
+Context, Scheduler, BlockManager, Sequence and Sampler. What is substituted (none of it can run
+here: no flash_attn package, no nvcc, no GPU): the two flash_attn calls and store_kvcache are the
+CPU oracle (oracle/attention_oracle.py), `lightvllm.kernels.cuda_kernels` is an empty module, and
+ModelRunner.prepare_prefill/prepare_decode (model_runner.py:271-418) are restated below without
+pin_memory/.cuda. Weights come from light_vllm_amd.utils.loader.random_checkpoint (seeded CPU
+normal draws keyed by tensor name), pushed through the reference's own weight loaders.
+
+Run in the build container only (TEST INFRASTRUCTURE; nothing in light_vllm_amd imports this):
+
+    TORCHDYNAMO_DISABLE=1 python oracle/gen_e2e_golden.py [--layers N] [--steps K]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+from types import SimpleNamespace
+
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REFERENCE)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from oracle import attention_oracle as orc  # noqa: E402
+
+
+def qwen3_0p6b_config(layers=28):
+    return SimpleNamespace(
+        vocab_size=151936, hidden_size=1024, intermediate_size=3072, num_hidden_layers=layers,
+        num_attention_heads=16, num_key_value_heads=8, head_dim=128, hidden_act="silu",
+        max_position_embeddings=40960, rms_norm_eps=1e-6, rope_theta=1000000, rope_scaling=None,
+        attention_bias=False, tie_word_embeddings=True, torch_dtype=torch.bfloat16,
+        kernel_backend="native")
+
+
+def config1_prompts():
+    g = torch.Generator().manual_seed(2026)
+    return [torch.randint(0, 151936, (256,), generator=g).tolist() for _ in range(4)]
+
+
+def install_stubs():
+    fa = types.ModuleType("flash_attn")
+
+    def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                               softmax_scale, causal, block_table=None):
+        assert causal
+        return orc.prefill_ref(q, k, v, cu_seqlens_q, cu_seqlens_k, softmax_scale, block_table).to(q.dtype)
+
+    def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, causal):
+        o = orc.decode_ref(q.squeeze(1), k_cache, v_cache, cache_seqlens, block_table, softmax_scale)
+        return o.to(q.dtype).unsqueeze(1)
+
+    fa.flash_attn_varlen_func = flash_attn_varlen_func
+    fa.flash_attn_with_kvcache = flash_attn_with_kvcache
+    sys.modules["flash_attn"] = fa
+    ck = types.ModuleType("lightvllm.kernels.cuda_kernels")
+    ck.cuda_swiglu = None
+    sys.modules["lightvllm.kernels.cuda_kernels"] = ck
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "e2e_config1.json"))
+    args = ap.parse_args()
+
+    install_stubs()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29611", world_size=1, rank=0)
+    import lightvllm.layers.attention as ref_attn
+    ref_attn.store_kvcache = orc.store_kvcache_ref
+    from lightvllm.engine.scheduler import Scheduler
+    from lightvllm.engine.sequence import Sequence
+    from lightvllm.layers.sampler import Sampler
+    from lightvllm.models.qwen3 import Qwen3ForCausalLM
+    from lightvllm.sampling_params import SamplingParams
+    from lightvllm.utils.context import reset_context, set_context
+    from light_vllm_amd.utils.loader import load_random
+
+    hf = qwen3_0p6b_config(args.layers)
+    torch.set_default_dtype(torch.bfloat16)
+    model = Qwen3ForCausalLM(hf)
+    torch.set_default_dtype(torch.float32)
+    load_random(model, hf, args.seed)
+    sampler = Sampler()
+
+    block_size, num_blocks = 256, 16
+    kv = torch.zeros(2, hf.num_hidden_layers, num_blocks, block_size, hf.num_key_value_heads, hf.head_dim,
+                     dtype=torch.bfloat16)
+    layer_id = 0
+    for m in model.modules():
+        if hasattr(m, "k_cache") and hasattr(m, "v_cache"):
+            m.k_cache, m.v_cache = kv[0, layer_id], kv[1, layer_id]
+            layer_id += 1
+
+    cfg = SimpleNamespace(max_num_seqs=512, max_num_batched_tokens=16384, eos=-1,
+                          num_kvcache_blocks=num_blocks, kvcache_block_size=block_size)
+    sch = Scheduler(cfg)
+    sp = SamplingParams(temperature=0.0, max_tokens=args.steps, ignore_eos=True)
+    prompts = config1_prompts()
+    seqs = [Sequence(p, sp) for p in prompts]
+    index = {id(s): i for i, s in enumerate(seqs)}
+    for s in seqs:
+        sch.add(s)
+
+    # prepare_* restated from engine/model_runner.py:256-418 (CPU tensors, no pinning)
+    def block_tables(batch):
+        w = max(len(s.block_table) for s in batch)
+        return torch.tensor([s.block_table + [-1] * (w - len(s.block_table)) for s in batch], dtype=torch.int32)
+
+    def prepare_prefill(batch):
+        ids, pos, cq, ck, slots = [], [], [0], [0], []
+        mq = mk = 0
+        for s in batch:
+            n = len(s)
+            ids.extend(s[s.num_cached_tokens:])
+            pos.extend(range(s.num_cached_tokens, n))
+            lq = n - s.num_cached_tokens
+            cq.append(cq[-1] + lq)
+            ck.append(ck[-1] + n)
+            mq, mk = max(mq, lq), max(mk, n)
+            for i in range(s.num_cached_blocks, s.num_blocks):
+                start = s.block_table[i] * block_size
+                end = start + (block_size if i != s.num_blocks - 1 else s.last_block_num_tokens)
+                slots.extend(range(start, end))
+        bt = block_tables(batch) if ck[-1] > cq[-1] else None
+        set_context(True, torch.tensor(cq, dtype=torch.int32), torch.tensor(ck, dtype=torch.int32), mq, mk,
+                    torch.tensor(slots, dtype=torch.int32), None, bt)
+        return torch.tensor(ids, dtype=torch.int64), torch.tensor(pos, dtype=torch.int64)
+
+    def prepare_decode(batch):
+        ids = [s.last_token for s in batch]
+        pos = [len(s) for s in batch]
+        slots = [s.block_table[-1] * block_size + s.last_block_num_tokens - 1 for s in batch]
+        set_context(False, slot_mapping=torch.tensor(slots, dtype=torch.int32),
+                    context_lens=torch.tensor(pos, dtype=torch.int32), block_tables=block_tables(batch))
+        return torch.tensor(ids, dtype=torch.int64), torch.tensor(pos, dtype=torch.int64)
+
+    steps = []
+    t0 = time.time()
+    with torch.inference_mode():
+        while not sch.is_finished():
+            batch, is_prefill = sch.schedule()
+            ids, pos = prepare_prefill(batch) if is_prefill else prepare_decode(batch)
+            logits = model.compute_logits(model(ids, pos)).float()
+            temps = torch.tensor([s.temperature for s in batch], dtype=torch.float32)
+            toks = sampler(logits.clone(), temps).tolist()
+            reset_context()
+            top_v, top_i = logits.topk(5, dim=-1)
+            steps.append({"prefill": is_prefill, "seqs": [index[id(s)] for s in batch], "tokens": toks,
+                          "gap": [round(float(x), 6) for x in (top_v[:, 0] - top_v[:, 1])],
+                          "top5": top_i.tolist(),
+                          "top5_logits": [[round(float(x), 5) for x in row] for row in top_v]})
+            sch.postprocess(batch, toks)
+            print(f"step {len(steps)} prefill={is_prefill} tokens={toks} t={time.time() - t0:.1f}s", flush=True)
+
+    out = {"model": "Qwen3-0.6B shapes, random init", "layers": args.layers, "seed": args.seed,
+           "weights": "light_vllm_amd.utils.loader.random_checkpoint(seed, std=0.02)",
+           "prompts_seed": 2026, "prompt_len": 256, "num_prompts": 4, "max_tokens": args.steps,
+           "dtype": "bfloat16", "steps": steps,
+           "completions": [list(s.completion_token_ids) for s in seqs]}
+    with open(args.out, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(f"wrote {args.out} ({os.path.getsize(args.out)} bytes) in {time.time() - t0:.1f}s")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

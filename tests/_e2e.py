@@ -1,0 +1,64 @@
+"""Shared driver for the end-to-end greedy parity tests: steps this package's Scheduler +
+ModelRunner through the reference run recorded in a golden file, teacher-forced, and compares
+each step's argmax with the reference's token (tie-aware)."""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN_DIR, name)) as f:
+        return json.load(f)
+
+
+def qwen3_0p6b_config(layers=28, dtype=torch.bfloat16):
+    return SimpleNamespace(
+        vocab_size=151936, hidden_size=1024, intermediate_size=3072, num_hidden_layers=layers,
+        num_attention_heads=16, num_key_value_heads=8, head_dim=128, hidden_act="silu",
+        max_position_embeddings=40960, rms_norm_eps=1e-6, rope_theta=1000000, rope_scaling=None,
+        attention_bias=False, tie_word_embeddings=True, torch_dtype=dtype)
+
+
+def config1_prompts(seed=2026, n=4, length=256):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 151936, (length,), generator=g).tolist() for _ in range(n)]
+
+
+def replay(golden, runner, scheduler, tie_gap):
+    """Returns (num_compared, mismatches) where a mismatch is tolerated only if the reference's
+    own top-2 logit gap at that step is below tie_gap and our token is in its top 5."""
+    from light_vllm_amd.engine.sequence import Sequence
+    from light_vllm_amd.sampling_params import SamplingParams
+    from light_vllm_amd.utils.context import reset_context
+    sp = SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"], ignore_eos=True)
+    prompts = config1_prompts(golden["prompts_seed"], golden["num_prompts"], golden["prompt_len"])
+    seqs = [Sequence(p, sp) for p in prompts]
+    index = {id(s): i for i, s in enumerate(seqs)}
+    for s in seqs:
+        scheduler.add(s)
+    compared, soft, hard = 0, [], []
+    for step_no, rec in enumerate(golden["steps"]):
+        batch, is_prefill = scheduler.schedule()
+        assert is_prefill == rec["prefill"], f"step {step_no}: phase differs"
+        assert [index[id(s)] for s in batch] == rec["seqs"], f"step {step_no}: batch differs"
+        ids, pos = runner.prepare_prefill(batch) if is_prefill else runner.prepare_decode(batch)
+        logits = runner.run_model(ids, pos, is_prefill).float()
+        reset_context()
+        ours = logits.argmax(-1).tolist()
+        for j, (a, b) in enumerate(zip(ours, rec["tokens"])):
+            compared += 1
+            if a != b:
+                item = (step_no, rec["seqs"][j], a, b, rec["gap"][j])
+                if rec["gap"][j] <= tie_gap and a in rec["top5"][j]:
+                    soft.append(item)
+                else:
+                    hard.append(item)
+        scheduler.postprocess(batch, rec["tokens"])     # teacher forcing with the reference tokens
+    assert scheduler.is_finished()
+    return compared, soft, hard

@@ -1,0 +1,44 @@
+"""BASELINE config 1 on CPU ("plumbing, no GPU"): this package's host stack with the three
+kernels substituted by the oracle, against the reference's stack run the same way
+(oracle/gen_e2e_golden.py --layers 2 --steps 8 -> tests/golden/e2e_small.json)."""
+import pytest
+import torch
+
+from tests._cpu_kernels import cpu_kernels
+from tests._e2e import load_golden, qwen3_0p6b_config, replay
+
+
+def _engine_parts(layers, seed):
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    cfg = Config(None, hf_config=qwen3_0p6b_config(layers), device="cpu", num_kvcache_blocks=16,
+                 max_model_len=512, max_num_batched_tokens=1024, random_seed=seed)
+    runner = ModelRunner(cfg, 0, [])
+    return cfg, runner, Scheduler(cfg)
+
+
+def test_config1_small_matches_reference_stack():
+    golden = load_golden("e2e_small.json")
+    with cpu_kernels():
+        cfg, runner, sch = _engine_parts(golden["layers"], golden["seed"])
+        compared, soft, hard = replay(golden, runner, sch, tie_gap=0.02)
+    assert compared == 4 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert len(soft) <= 1, f"too many tie flips: {soft}"
+
+
+def test_generate_api_cpu():
+    """LLM.generate end to end (free running) reproduces the reference completions."""
+    from light_vllm_amd.llm import LLM
+    from light_vllm_amd.sampling_params import SamplingParams
+    from tests._e2e import config1_prompts
+    golden = load_golden("e2e_small.json")
+    with cpu_kernels():
+        llm = LLM(None, hf_config=qwen3_0p6b_config(golden["layers"]), device="cpu", num_kvcache_blocks=16,
+                  max_model_len=512, max_num_batched_tokens=1024, random_seed=golden["seed"])
+        outs = llm.generate(config1_prompts(), SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"],
+                                                              ignore_eos=True))
+        llm.exit()
+    assert [o["token_ids"] for o in outs] == golden["completions"]
+    assert llm.last_stats["decode_tokens"] == 4 * (golden["max_tokens"] - 1)

@@ -1,0 +1,63 @@
+"""BASELINE config 1 end to end on the GPU: Qwen3-0.6B shapes, random init, 4 x 256-token prompts,
+64 greedy steps through the HIP kernels, against the reference stack's recorded run
+(tests/golden/e2e_config1.json, produced by oracle/gen_e2e_golden.py on CPU).
+
+The reference run used CPU bf16 GEMMs and the fp32 oracle attention, this run uses hipBLASLt GEMMs
+and the HIP kernels, so logits differ by bf16 rounding noise. The comparison is therefore
+teacher-forced (each step continues from the reference's token) and tie-aware: our argmax must
+equal the reference token unless the reference's own top-2 logit gap at that step is below
+TIE_GAP, in which case our token must still be one of its top 5."""
+import pytest
+import torch
+
+from tests._e2e import config1_prompts, load_golden, qwen3_0p6b_config, replay
+
+pytestmark = pytest.mark.gpu
+TIE_GAP = 0.08   # logits have std ~0.65 here; bf16 spacing near the top logits (~3) is 0.016
+
+
+def _parts(golden, enforce_eager):
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    cfg = Config(None, hf_config=qwen3_0p6b_config(golden["layers"]), num_kvcache_blocks=64,
+                 max_num_seqs=16, enforce_eager=enforce_eager, random_seed=golden["seed"])
+    runner = ModelRunner(cfg, 0, [])
+    return cfg, runner, Scheduler(cfg)
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
+def test_config1_teacher_forced_parity(gpu, enforce_eager):
+    golden = load_golden("e2e_config1.json")
+    cfg, runner, sch = _parts(golden, enforce_eager)
+    compared, soft, hard = replay(golden, runner, sch, tie_gap=TIE_GAP)
+    print(f"compared {compared} tokens, tie flips {soft}, hard mismatches {hard}")
+    runner.exit()
+    assert compared == 4 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert len(soft) <= compared // 20, f"too many tie flips: {soft}"
+
+
+def test_generate_free_running(gpu):
+    """LLM.generate (free running, hipGraph decode): every sequence must follow the reference
+    completion at least up to the first step where the reference itself was within TIE_GAP."""
+    from light_vllm_amd.llm import LLM
+    from light_vllm_amd.sampling_params import SamplingParams
+    golden = load_golden("e2e_config1.json")
+    llm = LLM(None, hf_config=qwen3_0p6b_config(golden["layers"]), num_kvcache_blocks=64, max_num_seqs=16,
+              enforce_eager=False, random_seed=golden["seed"])
+    outs = llm.generate(config1_prompts(), SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"],
+                                                          ignore_eos=True))
+    stats = llm.last_stats
+    llm.exit()
+    first_tie = [golden["max_tokens"]] * 4
+    for step_no, rec in enumerate(golden["steps"]):
+        for j, s in enumerate(rec["seqs"]):
+            if rec["gap"][j] <= TIE_GAP:
+                first_tie[s] = min(first_tie[s], step_no)
+    for s in range(4):
+        got, want = outs[s]["token_ids"], golden["completions"][s]
+        agree = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), len(want))
+        print(f"seq {s}: agrees for {agree}/{len(want)} tokens (first reference near-tie at step {first_tie[s]})")
+        assert agree >= first_tie[s]
+    assert stats["decode_tokens"] == 4 * (golden["max_tokens"] - 1)
