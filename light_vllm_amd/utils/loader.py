@@ -38,8 +38,8 @@ def load_model(model: nn.Module, path: str) -> None:
 def full_random_tensor(name: str, shape, seed: int, std: float) -> torch.Tensor:
     """The unsharded random value of checkpoint tensor `name`: a CPU fp32 normal draw seeded by
     (seed, crc32(name)), so every rank and every implementation derives identical weights."""
-    g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
-    return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+    g = torch.Generator(device="cpu").manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
+    return torch.randn(*shape, generator=g, dtype=torch.float32, device="cpu") * std
 
 
 def random_checkpoint(hf_config, seed: int = 0, std: float = 0.02):

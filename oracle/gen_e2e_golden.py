@@ -5,8 +5,8 @@ What runs from /root/reference: Qwen3ForCausalLM, the Attention.forward dispatch
 Context, Scheduler, BlockManager, Sequence and Sampler. What is substituted (none of it can run
 here: no flash_attn package, no nvcc, no GPU): the two flash_attn calls and store_kvcache are the
 CPU oracle (oracle/attention_oracle.py), `lightvllm.kernels.cuda_kernels` is an empty module, and
-ModelRunner.prepare_prefill/prepare_decode (model_runner.py:271-418) are restated below without
-pin_memory/.cuda. Weights come from light_vllm_amd.utils.loader.random_checkpoint (seeded CPU
+ModelRunner.prepare_prefill/prepare_decode (model_runner.py:271-418) are the restatement in
+oracle/host_oracle.py (no pin_memory/.cuda). Weights come from light_vllm_amd.utils.loader.random_checkpoint (seeded CPU
 normal draws keyed by tensor name), pushed through the reference's own weight loaders.
 
 Run in the build container only (TEST INFRASTRUCTURE; nothing in light_vllm_amd imports this):
@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from oracle import attention_oracle as orc  # noqa: E402
+from oracle import host_oracle as host  # noqa: E402
 
 
 def qwen3_0p6b_config(layers=28):
@@ -116,38 +117,21 @@ def main():
     for s in seqs:
         sch.add(s)
 
-    # prepare_* restated from engine/model_runner.py:256-418 (CPU tensors, no pinning)
-    def block_tables(batch):
-        w = max(len(s.block_table) for s in batch)
-        return torch.tensor([s.block_table + [-1] * (w - len(s.block_table)) for s in batch], dtype=torch.int32)
-
+    # step inputs: the restated prepare_* of oracle/host_oracle.py, as CPU tensors
     def prepare_prefill(batch):
-        ids, pos, cq, ck, slots = [], [], [0], [0], []
-        mq = mk = 0
-        for s in batch:
-            n = len(s)
-            ids.extend(s[s.num_cached_tokens:])
-            pos.extend(range(s.num_cached_tokens, n))
-            lq = n - s.num_cached_tokens
-            cq.append(cq[-1] + lq)
-            ck.append(ck[-1] + n)
-            mq, mk = max(mq, lq), max(mk, n)
-            for i in range(s.num_cached_blocks, s.num_blocks):
-                start = s.block_table[i] * block_size
-                end = start + (block_size if i != s.num_blocks - 1 else s.last_block_num_tokens)
-                slots.extend(range(start, end))
-        bt = block_tables(batch) if ck[-1] > cq[-1] else None
-        set_context(True, torch.tensor(cq, dtype=torch.int32), torch.tensor(ck, dtype=torch.int32), mq, mk,
-                    torch.tensor(slots, dtype=torch.int32), None, bt)
-        return torch.tensor(ids, dtype=torch.int64), torch.tensor(pos, dtype=torch.int64)
+        r = host.prepare_prefill_ref(batch, block_size)
+        bt = None if r["block_tables"] is None else torch.tensor(r["block_tables"], dtype=torch.int32)
+        set_context(True, torch.tensor(r["cu_seqlens_q"], dtype=torch.int32),
+                    torch.tensor(r["cu_seqlens_k"], dtype=torch.int32), r["max_seqlen_q"], r["max_seqlen_k"],
+                    torch.tensor(r["slot_mapping"], dtype=torch.int32), None, bt)
+        return torch.tensor(r["input_ids"], dtype=torch.int64), torch.tensor(r["positions"], dtype=torch.int64)
 
     def prepare_decode(batch):
-        ids = [s.last_token for s in batch]
-        pos = [len(s) for s in batch]
-        slots = [s.block_table[-1] * block_size + s.last_block_num_tokens - 1 for s in batch]
-        set_context(False, slot_mapping=torch.tensor(slots, dtype=torch.int32),
-                    context_lens=torch.tensor(pos, dtype=torch.int32), block_tables=block_tables(batch))
-        return torch.tensor(ids, dtype=torch.int64), torch.tensor(pos, dtype=torch.int64)
+        r = host.prepare_decode_ref(batch, block_size)
+        set_context(False, slot_mapping=torch.tensor(r["slot_mapping"], dtype=torch.int32),
+                    context_lens=torch.tensor(r["context_lens"], dtype=torch.int32),
+                    block_tables=torch.tensor(r["block_tables"], dtype=torch.int32))
+        return torch.tensor(r["input_ids"], dtype=torch.int64), torch.tensor(r["positions"], dtype=torch.int64)
 
     steps = []
     t0 = time.time()

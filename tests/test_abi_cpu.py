@@ -1,0 +1,84 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/lv_attention.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lv_attention.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert declared_functions() == sorted([
+        "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
+        "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn"])
+
+
+def test_library_exports_every_declared_symbol():
+    from light_vllm_amd import _lib
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} missing from liblvattn.so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_host_only_entry_points():
+    """Entry points that never touch the device can be called without one."""
+    from light_vllm_amd import _lib
+    lib = _lib.load()
+    assert lib.lv_abi_version() == _lib.ABI_VERSION
+    assert lib.lv_error_string(0) == b"ok"
+    assert lib.lv_error_string(-2) == b"unsupported configuration"
+    assert lib.lv_decode_workspace_bytes(4, 32, 128, 1) == 0
+    assert lib.lv_decode_workspace_bytes(4, 32, 128, 8) == 4 * 32 * 8 * 130 * 4
+    assert lib.lv_decode_workspace_bytes(4, 32, 64, 8) == 0
+    assert lib.lv_decode_num_splits(256, 8, 4) == 1          # enough (sequence, kv head) units already
+    assert lib.lv_decode_num_splits(1, 1, 128) == 128         # one long sequence: split down to blocks
+    assert lib.lv_decode_num_splits(8, 8, 128) == 16
+    assert lib.lv_decode_num_splits(1, 8, 1) == 1
+
+
+def test_argument_validation_happens_before_any_launch():
+    """Bad arguments are rejected on the host with a message (no GPU needed)."""
+    from light_vllm_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    # head_dim 64 is not supported
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 64, 0.1, None, 0, 1, None)
+    assert rc == -2 and b"head_dim" in lib.lv_last_error()
+    # block size must be a multiple of 32
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 48, 8, 8, 128, 0.1, None, 0, 1, None)
+    assert rc == -2
+    # split-KV without a workspace
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, 0.1, None, 0, 4, None)
+    assert rc == -4 and b"workspace" in lib.lv_last_error()
+    # misaligned key pointer
+    rc = lib.lv_store_kvcache(p16 + 2, p16, 1024, 1024, p16, p16, p16, 1, 8, 128, 256, None)
+    assert rc == -2
+    # row stride smaller than a row
+    rc = lib.lv_store_kvcache(p16, p16, 512, 1024, p16, p16, p16, 1, 8, 128, 256, None)
+    assert rc == -1
+    # heads not divisible
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, None)
+    assert rc == -1
+    # zero-size calls are no-ops
+    assert lib.lv_store_kvcache(None, None, 0, 0, None, None, None, 0, 8, 128, 256, None) == 0
+    assert lib.lv_decode_attn(None, None, None, None, 0, 0, None, None, 0, 0, 0, 256, 8, 8, 128, 0.1, None, 0, 1, None) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from light_vllm_amd import ops
+    x = torch.zeros(1, 8, 128, dtype=torch.bfloat16)
+    c = torch.zeros(1, 256, 8, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.store_kvcache(x, x, c, c, torch.zeros(1, dtype=torch.int32))

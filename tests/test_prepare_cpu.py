@@ -1,0 +1,121 @@
+"""Step-input builders (prepare_prefill / prepare_decode / prepare_block_tables) against the worked
+examples in the reference's docstrings and against the restatement in oracle/host_oracle.py."""
+import random
+
+import torch
+
+from light_vllm_amd.engine.block_manager import BlockManager
+from light_vllm_amd.engine.model_runner import ModelRunner
+from light_vllm_amd.engine.sequence import Sequence
+from light_vllm_amd.utils.context import get_context, reset_context
+from oracle.host_oracle import prepare_decode_ref, prepare_prefill_ref
+
+
+def _runner(block_size):
+    r = ModelRunner.__new__(ModelRunner)     # only the step-input builders are exercised
+    r.block_size = block_size
+    r.on_gpu = False
+    r.device = torch.device("cpu")
+    return r
+
+
+def _ctx_lists():
+    c = get_context()
+    f = lambda t: None if t is None else t.tolist()
+    return dict(cu_seqlens_q=f(c.cu_seqlens_q), cu_seqlens_k=f(c.cu_seqlens_k), max_seqlen_q=c.max_seqlen_q,
+                max_seqlen_k=c.max_seqlen_k, slot_mapping=f(c.slot_mapping), context_lens=f(c.context_lens),
+                block_tables=f(c.block_tables), is_prefill=c.is_prefill)
+
+
+def test_prefill_docstring_example():
+    """model_runner.py:294-304: block_size 4; seq0 = [10..14] with 4 cached tokens, seq1 = [20, 21]."""
+    Sequence.block_size = 4
+    try:
+        s0, s1 = Sequence([10, 11, 12, 13, 14]), Sequence([20, 21])
+        s0.num_cached_tokens, s0.block_table = 4, [3, 6]
+        s1.block_table = [2]
+        ids, pos = _runner(4).prepare_prefill([s0, s1])
+        c = _ctx_lists()
+        assert ids.tolist() == [14, 20, 21] and pos.tolist() == [4, 0, 1]
+        assert ids.dtype == torch.int64 and pos.dtype == torch.int64
+        assert c["cu_seqlens_q"] == [0, 1, 3] and c["cu_seqlens_k"] == [0, 5, 7]
+        assert c["max_seqlen_q"] == 2 and c["max_seqlen_k"] == 5
+        assert c["slot_mapping"] == [6 * 4 + 0, 2 * 4 + 0, 2 * 4 + 1]
+        assert c["block_tables"] == [[3, 6], [2, -1]] and c["context_lens"] is None and c["is_prefill"]
+        assert get_context().slot_mapping.dtype == torch.int32 and get_context().block_tables.dtype == torch.int32
+    finally:
+        Sequence.block_size = 256
+        reset_context()
+
+
+def test_slot_mapping_docstring_example():
+    """model_runner.py:357-363: block_table [5, 7, 9], one cached block, 2 tokens in the last block
+    -> slots [28, 29, 30, 31, 36, 37]."""
+    Sequence.block_size = 4
+    try:
+        s = Sequence(list(range(10)))
+        s.num_cached_tokens, s.block_table = 4, [5, 7, 9]
+        _runner(4).prepare_prefill([s])
+        assert _ctx_lists()["slot_mapping"] == [28, 29, 30, 31, 36, 37]
+    finally:
+        Sequence.block_size = 256
+        reset_context()
+
+
+def test_no_prefix_hit_means_no_block_tables():
+    s = Sequence(list(range(300)))
+    s.block_table = [4, 1]
+    _runner(256).prepare_prefill([s])
+    c = _ctx_lists()
+    assert c["block_tables"] is None and c["cu_seqlens_q"] == c["cu_seqlens_k"] == [0, 300]
+    assert c["slot_mapping"] == list(range(4 * 256, 5 * 256)) + list(range(256, 256 + 44))
+    reset_context()
+
+
+def test_decode_first_step_after_a_full_block():
+    """config-1 geometry: 256-token prompt + 1 sampled token -> len 257, new block, slot offset 0,
+    RoPE position len(seq) as the reference feeds it."""
+    s = Sequence(list(range(256)))
+    s.block_table = [7]
+    s.append_token(99)
+    s.block_table.append(3)
+    ids, pos = _runner(256).prepare_decode([s])
+    c = _ctx_lists()
+    assert ids.tolist() == [99] and pos.tolist() == [257]
+    assert c["context_lens"] == [257] and c["slot_mapping"] == [3 * 256] and c["block_tables"] == [[7, 3]]
+    assert not c["is_prefill"]
+    reset_context()
+
+
+def test_random_batches_match_restatement():
+    rng = random.Random(0)
+    Sequence.block_size = 16
+    try:
+        for trial in range(20):
+            bm = BlockManager(64, 16)
+            shared = [rng.randrange(1000) for _ in range(32)]
+            seqs = []
+            for _ in range(rng.randrange(1, 6)):
+                toks = (shared if rng.random() < 0.5 else []) + [rng.randrange(1000) for _ in range(rng.randrange(1, 40))]
+                s = Sequence(toks)
+                bm.allocate(s)
+                seqs.append(s)
+            r = _runner(16)
+            ids, pos = r.prepare_prefill(seqs)
+            want = prepare_prefill_ref(seqs, 16)
+            c = _ctx_lists()
+            assert ids.tolist() == want["input_ids"] and pos.tolist() == want["positions"]
+            for k in ("cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "slot_mapping", "block_tables"):
+                assert c[k] == want[k], (trial, k)
+            for s in seqs:
+                s.append_token(rng.randrange(1000))
+                bm.may_append(s)
+            ids, pos = r.prepare_decode(seqs)
+            want = prepare_decode_ref(seqs, 16)
+            c = _ctx_lists()
+            assert ids.tolist() == want["input_ids"] and pos.tolist() == want["positions"]
+            for k in ("context_lens", "slot_mapping", "block_tables"):
+                assert c[k] == want[k], (trial, k)
+    finally:
+        Sequence.block_size = 256
+        reset_context()
