@@ -17,6 +17,8 @@
 //     with lane^32, and the bf16-rounded P registers are directly the B operand of
 //     O^T += V^T P^T (same lane = same query row), with no LDS round trip for P.
 //   * fp32 scores, statistics and accumulation; exp2 with scale*log2(e) folded into one FMA.
+#include <stdlib.h>
+
 #include "lv_kernels.h"
 
 namespace lv {
@@ -24,8 +26,9 @@ namespace lv {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;  // LDS-typed pointers keep
+// constant offsets in the ds_* instructions' immediate field instead of one address VGPR per read
 
-constexpr int BM = 128;  // query rows per workgroup
 constexpr int BN = 64;   // keys per staged tile
 constexpr int kTileBytes = BN * kHeadDim * 2;  // 16 KiB
 
@@ -34,11 +37,44 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <bool PAGED>
-__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const PrefillParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileBytes];
-  unsigned char* const lds_k = lds;
-  unsigned char* const lds_v = lds + kTileBytes;
+// Diagnostic builds (-DLV_STAMPS, tools/prefill_diag.hip) accumulate s_memtime deltas per loop
+// segment; the shipped library compiles these macros to nothing.
+#ifdef LV_STAMPS
+__device__ unsigned long long* g_lv_stamp_buf = nullptr;
+#define LV_STAMP_DECL unsigned long long st_prev, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0);
+#define LV_STAMP(i) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); \
+  st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define LV_STAMP_FLUSH if (g_lv_stamp_buf && lane == 0) { \
+  unsigned long long* d = g_lv_stamp_buf + ((static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 8; \
+  for (int i = 0; i < 8; ++i) d[i] = st_acc[i]; }
+#else
+#define LV_STAMP_DECL
+#define LV_STAMP(i)
+#define LV_STAMP_FLUSH
+#endif
+
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+// Rescale of the running output is skipped while no row's maximum grows by more than this many
+// powers of two; P then reaches at most 2^kDeferLog2 instead of 1, which fp32 sums and the bf16
+// P operand (same relative precision at any magnitude) absorb.
+constexpr float kDeferLog2 = 6.0f;
+
+// NW = waves per workgroup, RB = 32-row query blocks per wave; the workgroup's query tile is
+// 32*RB*NW rows. Only RB = 1 is instantiated: with RB = 2 (each K/V fragment feeding two MFMAs,
+// one wave per SIMD) hipcc parks values in AGPRs and pays v_accvgpr_read/write copies around every
+// MFMA, which measured 30 % slower than RB = 1 at two waves per SIMD.
+template <bool PAGED, int NW, int RB>
+__global__ __launch_bounds__(64 * NW, (RB == 2 ? 1 : 2))
+void prefill_attn_kernel(const PrefillParams p) {
+  constexpr int BM = 32 * RB * NW;  // query rows per workgroup
+  constexpr int NST = 16 / NW;      // 16-byte chunks of K (and of V) each thread stages per tile
+  constexpr int RSTEP = 4 * NW;     // tile rows between two chunks of one thread
+  // two buffers x (K tile | V tile)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
 
   const int b = blockIdx.z;
   const int hq = blockIdx.y;
@@ -56,184 +92,297 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(const PrefillParam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int h = lane >> 5;  // which 8-wide half of an MFMA k-step this lane feeds
-  const int c = lane & 31;  // MFMA column = query row inside the wave's 32 rows
+  const int c = lane & 31;  // MFMA column = query row inside a 32-row block
 
-  const int wrow0 = q0 + wave * 32;
-  const int my_row = wrow0 + c;
-  const int my_lim = my_row + coff;  // last visible key of this lane's row
-  const int row_ld = min(my_row, Lq - 1);
+  const int wrow0 = q0 + wave * (32 * RB);  // first row of the wave; block rb starts 32*rb later
+  int my_lim[RB];                           // last visible key of this lane's row in block rb
 
-  // Q^T fragments (B operand of S^T = K Q^T): 8 k-steps x 8 bf16.
-  bf16x8 qf[8];
-  {
+  // Q^T fragments (B operand of S^T = K Q^T): per row block 8 k-steps x 8 bf16.
+  bf16x8 qf[RB][8];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int my_row = wrow0 + 32 * rb + c;
+    my_lim[rb] = my_row + coff;
+    const int row_ld = min(my_row, Lq - 1);
     const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 8; ++s) qf[rb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
   const int ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
 
-  // staging role of this thread: chunk st_ch of rows st_r + 16*i, i = 0..3
+  // ---- staging: this thread moves chunk st_ch of tile rows st_r + RSTEP*i (i < NST).
+  // Address = wave-uniform tile base (scalar registers) + a per-thread byte offset that is the
+  // same for every tile, so the loop carries no 64-bit vector address arithmetic.
   const int st_ch = tid & 15;
   const int st_r = tid >> 4;
   const int32_t* bt_row = PAGED ? p.block_table + static_cast<int64_t>(b) * p.bt_stride : nullptr;
+  const uint32_t k_row_bytes = static_cast<uint32_t>(p.k_stride0) * 2u;
+  const uint32_t v_row_bytes = static_cast<uint32_t>(p.v_stride0) * 2u;
+  const uint32_t col_bytes = static_cast<uint32_t>(kvh * kHeadDim + 8 * st_ch) * 2u;
+  const uint32_t st_koff = static_cast<uint32_t>(st_r) * k_row_bytes + col_bytes;
+  const uint32_t st_voff = static_cast<uint32_t>(st_r) * v_row_bytes + col_bytes;
+  const int st_lds = lds_off(st_r, st_ch);  // rows st_r + RSTEP*i share the swizzle term: + 256*RSTEP*i
 
-  u32x4 kreg[4], vreg[4];
+  u32x4 kreg[NST], vreg[NST];
   auto stage_load = [&](int tile) {
     const int kt0 = tile * BN;
-    int64_t base_row;  // cache/packed row index of key kt0
+    int64_t base_row;  // cache / packed row index of key kt0 (wave-uniform)
     if constexpr (PAGED) {
       const int blk = bt_row[kt0 / p.block_size];
       base_row = static_cast<int64_t>(blk) * p.block_size + (kt0 % p.block_size);
     } else {
       base_row = static_cast<int64_t>(k_start) + kt0;
     }
-    const int last = Lk - 1 - kt0;  // rows past the sequence end re-read its last row (masked later)
+    const char* kb = reinterpret_cast<const char*>(p.k) + base_row * k_row_bytes;
+    const char* vb = reinterpret_cast<const char*>(p.v) + base_row * v_row_bytes;
+    if (kt0 + BN <= Lk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = min(st_r + 16 * i, last);
-      const int64_t row = base_row + r;
-      kreg[i] = *reinterpret_cast<const u32x4*>(p.k + row * p.k_stride0 + kvh * kHeadDim + 8 * st_ch);
-      vreg[i] = *reinterpret_cast<const u32x4*>(p.v + row * p.v_stride0 + kvh * kHeadDim + 8 * st_ch);
+      for (int i = 0; i < NST; ++i) {
+        kreg[i] = *reinterpret_cast<const u32x4*>(kb + static_cast<uint64_t>(RSTEP * i) * k_row_bytes + st_koff);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vb + static_cast<uint64_t>(RSTEP * i) * v_row_bytes + st_voff);
+      }
+    } else {
+      // last, partial tile: rows past the sequence end re-read its last row (masked later)
+      const int last = Lk - 1 - kt0;
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const uint32_t r = static_cast<uint32_t>(min(st_r + RSTEP * i, last));
+        kreg[i] = *reinterpret_cast<const u32x4*>(kb + r * k_row_bytes + col_bytes);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vb + r * v_row_bytes + col_bytes);
+      }
     }
   };
-  auto stage_write = [&]() {
+  auto stage_write = [&](auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = lds_off(st_r + 16 * i, st_ch);
-      *reinterpret_cast<u32x4*>(lds_k + off) = kreg[i];
-      *reinterpret_cast<u32x4*>(lds_v + off) = vreg[i];
+    for (int i = 0; i < NST; ++i) {
+      *reinterpret_cast<u32x4*>(lds + BUF * 2 * kTileBytes + 256 * RSTEP * i + st_lds) = kreg[i];
+      *reinterpret_cast<u32x4*>(lds + BUF * 2 * kTileBytes + kTileBytes + 256 * RSTEP * i + st_lds) = vreg[i];
     }
   };
 
-  f32x16 oacc[4];
+  f32x16 oacc[RB][4];
+  float m_run[RB], l_run[RB];  // running row max (raw score units); this lane's share of the row sum
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    m_run[rb] = -INFINITY;
+    l_run[rb] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[rb][dt][r] = 0.f;
+  }
+
+  const float cexp = p.scale_log2e;
+  const float defer_raw = kDeferLog2 / cexp;  // threshold in raw score units
+
+  // LDS read addresses inside buffer 0 (everything else is a compile-time offset):
+  //   K as A operand: row c of a 32-key sub-tile, chunk (2s+h) swizzled with the row   -> 8 bases
+  //   V^T as A operand (ds_read_b64_tr_b16, per 16-lane group): lane 4q+p of group gi addresses
+  //   row 8*second + 4*(gi>>1) + q, columns 32*dt + 16*(gi&1) + 4p .. +3                 -> 8 bases
+  lds_byte* const lds3 = (lds_byte*)lds;
+  const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
+  const int gi = lane >> 4;
+  const int tq = (lane & 15) >> 2;
+  const int tp = lane & 3;
+  lds_byte* kaddr[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) kaddr[s] = lds3 + 256 * c + 16 * ((2 * s + h) ^ xr);
+  lds_byte* vaddr[4][2];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float m_run = -INFINITY;  // running row max, raw score units
-  float l_run = 0.f;        // this lane's share of the row sum (keys with its h)
-
-  const float cexp = p.scale_log2e;
-
-  // transposed-read lane roles (ds_read_b64_tr_b16 works per 16-lane group)
-  const int gi = lane >> 4;        // group: h = gi>>1, d half = gi&1
-  const int tq = (lane & 15) >> 2;  // row of the 4x16 block this lane addresses
-  const int tp = lane & 3;          // 4-column piece of that row
-
-  if (ntiles > 0) stage_load(0);
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int kt0 = tile * BN;
-    __syncthreads();  // every wave is done reading the previous tile
-    stage_write();
-    __syncthreads();
-    if (tile + 1 < ntiles) stage_load(tile + 1);
-
-    // waves whose rows all lie above this tile have nothing to add
-    if (kt0 > wrow0 + 31 + coff) continue;
-
-    // ---- S^T = K Q^T : 2 sub-tiles of 32 keys
-    f32x16 sacc[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds_k + lds_off(32 * sub + c, 2 * s + h));
-        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[sub], 0, 0, 0);
-      }
+    for (int second = 0; second < 2; ++second) {
+      const int row = 8 * second + 4 * (gi >> 1) + tq;
+      const int ch = 4 * dt + 2 * (gi & 1) + (tp >> 1);
+      vaddr[dt][second] = lds3 + kTileBytes + lds_off(row, ch) + 8 * (tp & 1);
     }
-    // ---- causal mask (only tiles that reach past the wave's first row limit)
-    if (kt0 + BN - 1 > wrow0 + coff) {
+
+  LV_STAMP_DECL
+
+  // ---- pieces of one 32-key online-softmax step for row block rb
+  // S^T = K Q^T
+  auto qk = [&](const bf16x8 (&ka)[8], int rb, f32x16& sacc) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt0 + 32 * sub + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (key > my_lim) sacc[sub][r] = -INFINITY;
-        }
-    }
-    // ---- online softmax for this lane's query row
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * cexp);
-    const float mc = m_use * cexp;
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int s = 0; s < 8; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[rb][s], sacc, 0, 0, 0);
+  };
+  // causal mask, row maximum and (rarely) rescale of the running state; returns max * scale*log2e
+  auto softmax_head = [&](int ks0, int rb, f32x16& sacc) -> float {
+    if (ks0 + 31 > wrow0 + 32 * rb + coff) {  // only sub-tiles that reach past the block's first row limit
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[sub][r], cexp, -mc));
-        psum += pe;
-        pf[sub][r >> 3][r & 7] = static_cast<__bf16>(pe);
+        const int key = ks0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (key > my_lim[rb]) sacc[r] = -INFINITY;
       }
-    l_run = l_run * alpha + psum;
+    }
+    float mx = sacc[0];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+    {
+      // exchange with lane ^ 32 on the VALU (v_permlane32_swap): no LDS round trip
+      const unsigned mb = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    // Rescale only when some row of the wave outgrows its running maximum by more than the
+    // deferral threshold (always true on a row's first visible keys: m_run = -inf).
+    if (__builtin_amdgcn_ballot_w64(mx - m_run[rb] > defer_raw) != 0) {
+      const float m_new = fmaxf(m_run[rb], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run[rb] - m_use) * cexp);
+      m_run[rb] = m_new;
+      l_run[rb] *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[rb][dt][r] *= alpha;
+    }
+    return ((m_run[rb] == -INFINITY) ? 0.f : m_run[rb]) * cexp;
+  };
+  // P = exp2(S*c - m*c), row-sum share, bf16 P fragments (the B operand of O^T += V^T P^T)
+  auto softmax_tail = [&](int rb, const f32x16& sacc, float mc, bf16x8 (&pf)[2]) {
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
+      psum += pe;
+      pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
+    }
+    l_run[rb] += psum;
+  };
+  auto pv = [&](const bf16x8 (&va)[2][4], int rb, const bf16x8 (&pf)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        oacc[rb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pf[s], oacc[rb][dt], 0, 0, 0);
+  };
+  auto compute = [&](int tile, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr int kBufOff = BUF * 2 * kTileBytes;
+    const int kt0 = tile * BN;
+    // waves whose rows all lie above this tile have nothing to add
+    if (kt0 > wrow0 + 32 * RB - 1 + coff) return;
 
-    // ---- O^T += V^T P^T
+    // The 64-key tile is consumed as two 32-key online-softmax steps, which keeps S at 16
+    // registers per row block and leaves room to fetch every MFMA operand of a step early.
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < 2; ++sub) {
+      const int ks0 = kt0 + 32 * sub;
+      // K rows of this sub-tile (A operand of S^T = K Q^T), all 8 k-steps in flight at once
+      bf16x8 ka[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        ka[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kaddr[s] + kBufOff + 8192 * sub);
+      f32x16 sacc[RB];
+      bf16x8 pf[RB][2];
+      qk(ka, 0, sacc[0]);
+      if constexpr (RB == 1) __builtin_amdgcn_sched_barrier(0);  // K fragments dead; V fragments reuse their registers
+
+      // V^T fragments of this sub-tile (A operand of O^T += V^T P^T): issued now, consumed after
+      // the softmax below, so their LDS latency hides under it.
+      bf16x8 va[2][4];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          bf16x8 a;
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
           for (int second = 0; second < 2; ++second) {
-            const int row = 32 * sub + 16 * s + 8 * second + 4 * (gi >> 1) + tq;
-            const int ch = 4 * dt + 2 * (gi & 1) + (tp >> 1);
             const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                 reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(
-                    reinterpret_cast<uintptr_t>(lds_v + lds_off(row, ch) + 8 * (tp & 1))));
-            a[4 * second + 0] = t[0];
-            a[4 * second + 1] = t[1];
-            a[4 * second + 2] = t[2];
-            a[4 * second + 3] = t[3];
+                    vaddr[dt][second] + kBufOff + 256 * (32 * sub + 16 * s)));
+            va[s][dt][4 * second + 0] = t[0];
+            va[s][dt][4 * second + 1] = t[1];
+            va[s][dt][4 * second + 2] = t[2];
+            va[s][dt][4 * second + 3] = t[3];
           }
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[sub][s], oacc[dt], 0, 0, 0);
-        }
-  }
-
-  // ---- epilogue: normalise and store this lane's row (d = 32*dt + (r&3) + 8*(r>>2) + 4*h)
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (my_row < Lq) {
-    uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
+      LV_STAMP(4)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        u32x2 w;
-        w[0] = pack_bf16x2(oacc[dt][4 * rg + 0] * inv, oacc[dt][4 * rg + 1] * inv);
-        w[1] = pack_bf16x2(oacc[dt][4 * rg + 2] * inv, oacc[dt][4 * rg + 3] * inv);
-        *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * rg) = w;
+      for (int rb = 0; rb < RB; ++rb) {
+        if (rb > 0) qk(ka, rb, sacc[rb]);
+        const float mc = softmax_head(ks0, rb, sacc[rb]);
+        softmax_tail(rb, sacc[rb], mc, pf[rb]);
       }
+      LV_STAMP(5)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pv(va, rb, pf[rb]);
+      LV_STAMP(6)
+    }
+  };
+
+  // ---- main loop: tile t is computed from buffer t&1 while tile t+1 sits in registers and tile
+  // t+2's loads are in flight; one workgroup barrier per tile.
+  if (ntiles > 0) {
+    stage_load(0);
+    stage_write(IntC<0>{});
+    __syncthreads();
+    if (ntiles > 1) stage_load(1);
+  }
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    LV_STAMP(3)
+    compute(tile, IntC<0>{});
+    if (tile + 1 < ntiles) stage_write(IntC<1>{});
+    LV_STAMP(1)
+    __syncthreads();
+    LV_STAMP(0)
+    if (tile + 2 < ntiles) stage_load(tile + 2);
+    if (tile + 1 < ntiles) {
+      LV_STAMP(3)
+      compute(tile + 1, IntC<1>{});
+      if (tile + 2 < ntiles) stage_write(IntC<0>{});
+      LV_STAMP(1)
+      __syncthreads();
+      LV_STAMP(0)
+      if (tile + 3 < ntiles) stage_load(tile + 3);
+    }
+  }
+  LV_STAMP_FLUSH
+
+  // ---- epilogue: normalise and store this lane's rows (d = 32*dt + (r&3) + 8*(r>>2) + 4*h)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int my_row = wrow0 + 32 * rb + c;
+    if (my_row < Lq) {
+      uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          u32x2 w;
+          w[0] = pack_bf16x2(oacc[rb][dt][4 * rg + 0] * inv, oacc[rb][dt][4 * rg + 1] * inv);
+          w[1] = pack_bf16x2(oacc[rb][dt][4 * rg + 2] * inv, oacc[rb][dt][4 * rg + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * rg) = w;
+        }
+    }
   }
 }
 
-int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
+template <bool PAGED, int NW, int RB>
+static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
+  constexpr int BM = 32 * RB * NW;
   const unsigned qtiles = static_cast<unsigned>((p.max_seqlen_q + BM - 1) / BM);
+  const dim3 grid(qtiles, static_cast<unsigned>(p.num_heads), static_cast<unsigned>(p.batch));
+  hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB>), grid, dim3(64 * NW), 0, stream, p);
+}
+
+int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   if (p.batch > 65535 || p.num_heads > 65535)
     return fail(LV_ERR_UNSUPPORTED, "prefill: batch or num_heads > 65535");
-  const dim3 grid(qtiles, static_cast<unsigned>(p.num_heads), static_cast<unsigned>(p.batch));
+  // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
+  //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row.
+  static const int force = getenv("LV_PREFILL_CFG") ? atoi(getenv("LV_PREFILL_CFG")) : -1;
+  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 1024 ? 1 : 0);
   if (p.block_table) {
-    hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, dim3(256), 0, stream, p);
+    if (cfg == 1) launch_cfg<true, 8, 1>(p, stream); else launch_cfg<true, 4, 1>(p, stream);
   } else {
-    hipLaunchKernelGGL(prefill_attn_kernel<false>, grid, dim3(256), 0, stream, p);
+    if (cfg == 1) launch_cfg<false, 8, 1>(p, stream); else launch_cfg<false, 4, 1>(p, stream);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "prefill_attn launch: %s", hipGetErrorString(e));

@@ -98,6 +98,13 @@ def main():
         rows.append(prefill_case([4096, 3000, 1024, 8264], 32, 8))
         rows.append(prefill_case([1024] * 16, 16, 8))
         rows.append(prefill_case([4096] * 4, 8, 1))
+    if args.what == "prefill1":
+        rows.append(prefill_case([4096] * 4, 32, 8))
+    if args.what == "decode_g8":
+        rows.append(decode_case(256, 1024, 64, 8))
+    if args.what == "decode_small":
+        rows.append(decode_case(1, 32768, 4, 1))
+        rows.append(decode_case(8, 32768, 16, 4))
     for r in rows:
         print(json.dumps(r), flush=True)
 

@@ -1,0 +1,72 @@
+// Diagnostic harness (not shipped): builds the prefill kernel with s_memtime stamps and prints the
+// share of wave time spent in each loop segment. Build and run:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLV_STAMPS -Iinclude -Ilight_vllm_amd/csrc \
+//         tools/prefill_diag.hip -o tools/prefill_diag && tools/prefill_diag
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../light_vllm_amd/csrc/prefill_attn.hip"
+
+namespace lv {
+int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
+  return code;
+}
+}  // namespace lv
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+static uint16_t rnd_bf16(uint64_t& s) {
+  s = s * 6364136223846793005ull + 1442695040888963407ull;
+  float f = ((int)((s >> 40) & 0xffff) - 32768) / 16384.0f;  // roughly uniform [-2, 2)
+  uint32_t u; memcpy(&u, &f, 4);
+  return (uint16_t)(u >> 16);
+}
+
+int main(int argc, char** argv) {
+  const int B = 4, L = argc > 1 ? atoi(argv[1]) : 4096, Hq = 32, Hkv = 8, D = 128;
+  const size_t nq = (size_t)B * L * Hq * D, nk = (size_t)B * L * Hkv * D;
+  std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
+  uint64_t seed = 1;
+  for (auto& x : hq) x = rnd_bf16(seed);
+  for (auto& x : hk) x = rnd_bf16(seed);
+  for (auto& x : hv) x = rnd_bf16(seed);
+  std::vector<int> cu(B + 1);
+  for (int i = 0; i <= B; ++i) cu[i] = i * L;
+  uint16_t *dq, *dk, *dv, *dout; int* dcu; unsigned long long* dst;
+  CK(hipMalloc(&dq, nq * 2)); CK(hipMalloc(&dk, nk * 2)); CK(hipMalloc(&dv, nk * 2)); CK(hipMalloc(&dout, nq * 2));
+  CK(hipMalloc(&dcu, (B + 1) * 4));
+  CK(hipMemcpy(dq, hq.data(), nq * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dk, hk.data(), nk * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dv, hv.data(), nk * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dcu, cu.data(), (B + 1) * 4, hipMemcpyHostToDevice));
+  const int qtiles = (L + 127) / 128;
+  const size_t nst = (size_t)B * Hq * qtiles * 64;
+  CK(hipMalloc(&dst, nst * 8)); CK(hipMemset(dst, 0, nst * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(lv::g_lv_stamp_buf), &dst, sizeof(dst)));
+  lv::PrefillParams p{};
+  p.q = dq; p.k = dk; p.v = dv; p.o = dout;
+  p.q_stride0 = p.o_stride0 = Hq * D; p.k_stride0 = p.v_stride0 = Hkv * D;
+  p.cu_q = dcu; p.cu_k = dcu; p.block_table = nullptr; p.bt_stride = 0; p.block_size = 0;
+  p.batch = B; p.max_seqlen_q = L; p.num_heads = Hq; p.num_kv_heads = Hkv;
+  p.scale_log2e = 0.08838834764f * 1.4426950408889634f;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 3; ++it) {
+    CK(hipEventRecord(e0));
+    if (lv::launch_prefill_attn(p, nullptr) != 0) return 1;
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("run %d: %.3f ms (stamped build; not a performance number)\n", it, ms);
+  }
+  std::vector<unsigned long long> st(nst);
+  CK(hipMemcpy(st.data(), dst, nst * 8, hipMemcpyDeviceToHost));
+  double seg[8] = {0}; double tot = 0;
+  for (size_t i = 0; i < nst; ++i) { seg[i % 8] += (double)st[i]; tot += (double)st[i]; }
+  const char* names[8] = {"barrier A (wait readers)", "ds_write stage", "barrier B", "issue next loads",
+                          "QK^T (LDS reads + 16 MFMA)", "mask + softmax", "PV (tr reads + 16 MFMA)", "-"};
+  for (int i = 0; i < 7; ++i) printf("%-30s %6.2f %%\n", names[i], 100.0 * seg[i] / tot);
+  const double tiles = 0; (void)tiles;
+  return 0;
+}
