@@ -118,7 +118,7 @@ def main():
     bt, ctx, slots = bt_cpu.to(dev), ctx_cpu.to(dev), slots_cpu.to(dev)
     scale = D ** -0.5
     out = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
-    nsplit = ops.decode_num_splits(B, Hkv, blocks_per_seq)
+    nsplit = ops.decode_num_splits(B, Hkv, blocks_per_seq, BLOCK)
     ops.reserve_decode_workspace(dev, ops.decode_workspace_bytes(B, Hq, D, nsplit))
 
     def step(events=None):

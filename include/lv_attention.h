@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 1
+#define LV_ABI_VERSION 2
 
 typedef void* lv_stream_t;
 
@@ -110,7 +110,7 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
  * Split count lv_decode_attn will use when called with num_splits == 0, for these static
  * shapes (it never depends on device data, so it is stable under hipGraph replay).
  */
-int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq);
+int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size);
 
 /*
  * Bytes of device workspace lv_decode_attn needs for (batch, num_heads, num_splits).

@@ -20,15 +20,17 @@ int fail(int code, const char* fmt, ...) {
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kMaxSplits = 128;
+constexpr int kMaxSplits = 512;
+constexpr int kSplitUnitTokens = 64;  // split granularity of the decode kernel
 constexpr int kTargetWorkgroups = 1024;  // 256 CUs x 4 resident 256-thread workgroups
 
-static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq) {
+static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
-  if (units <= 0 || max_blocks_per_seq <= 1) return 1;
+  if (units <= 0 || max_blocks_per_seq <= 0) return 1;
   if (units >= kTargetWorkgroups) return 1;
   int64_t n = (kTargetWorkgroups + units - 1) / units;
-  if (n > max_blocks_per_seq) n = max_blocks_per_seq;
+  const int64_t max_units = (static_cast<int64_t>(max_blocks_per_seq) * block_size + kSplitUnitTokens - 1) / kSplitUnitTokens;
+  if (n > max_units) n = max_units;
   if (n > kMaxSplits) n = kMaxSplits;
   return n < 1 ? 1 : static_cast<int>(n);
 }
@@ -128,8 +130,8 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
   return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
 }
 
-int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq) {
-  return heuristic_splits(batch, num_kv_heads, max_blocks_per_seq);
+int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {
+  return heuristic_splits(batch, num_kv_heads, max_blocks_per_seq, block_size > 0 ? block_size : 256);
 }
 
 size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num_splits) {
@@ -161,7 +163,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
   if (q_stride0 % 8 != 0 || o_stride0 % 8 != 0 || !aligned16(q) || !aligned16(o) ||
       !aligned16(k_cache) || !aligned16(v_cache))
     return fail(LV_ERR_UNSUPPORTED, "decode: q/o/caches must be 16-byte aligned with strides %% 8 == 0");
-  int nsplit = num_splits == 0 ? heuristic_splits(batch, num_kv_heads, max_blocks_per_seq) : num_splits;
+  int nsplit = num_splits == 0 ? heuristic_splits(batch, num_kv_heads, max_blocks_per_seq, block_size) : num_splits;
   if (nsplit > kMaxSplits) return fail(LV_ERR_INVALID_ARGUMENT, "decode: num_splits %d > %d", nsplit, kMaxSplits);
   if (static_cast<int64_t>(batch) * num_kv_heads * nsplit > INT32_MAX)
     return fail(LV_ERR_UNSUPPORTED, "decode: grid too large");

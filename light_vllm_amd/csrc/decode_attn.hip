@@ -20,6 +20,11 @@
 namespace lv {
 
 
+// Split boundaries are multiples of this many tokens: a multiple of every chunk size 4*U used
+// below and a divisor-compatible unit for block sizes that are multiples of 32 (a chunk of 4*U
+// tokens starting at a multiple of 4*U never straddles two blocks).
+constexpr int kSplitUnit = 64;
+
 template <bool NT>
 __device__ __forceinline__ u32x4 load16(const uint16_t* p) {
   if constexpr (NT) {
@@ -50,11 +55,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
 
   const int BS = p.block_size;
   const int ctx = p.context_lens[b];
-  const int nblk = (ctx + BS - 1) / BS;
-  const int blo = static_cast<int>(static_cast<int64_t>(split) * nblk / nsplit);
-  const int bhi = static_cast<int>(static_cast<int64_t>(split + 1) * nblk / nsplit);
-  const int t0 = blo * BS;
-  const int t1 = min(bhi * BS, ctx);
+  // splits divide the sequence's actual length evenly, in units of kSplitUnit tokens
+  const int nunits = (ctx + kSplitUnit - 1) / kSplitUnit;
+  const int ulo = static_cast<int>(static_cast<int64_t>(split) * nunits / nsplit);
+  const int uhi = static_cast<int>(static_cast<int64_t>(split + 1) * nunits / nsplit);
+  const int t0 = ulo * kSplitUnit;
+  const int t1 = min(uhi * kSplitUnit, ctx);
   const int ntok = t1 - t0;
   const int nchunks = ntok > 0 ? (ntok + TOK - 1) / TOK : 0;
 
@@ -248,28 +254,60 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
   }
 }
 
-// Combine the nsplit partial results of one (sequence, query head): one block of 128 lanes.
-__global__ __launch_bounds__(128) void decode_merge_kernel(const float* __restrict__ ws_o,
+// Combine the nsplit partial results of one (sequence, query head). 256 lanes = 8 groups of 32;
+// a lane owns 4 output dims (one 16-byte load per split) and its group walks splits g, g+8, ...,
+// so many independent loads are in flight; groups are merged through LDS.
+__global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ ws_o,
                                                            const float* __restrict__ ws_ml,
                                                            uint16_t* __restrict__ o,
                                                            int64_t o_stride0, int num_heads,
                                                            int nsplit) {
+  __shared__ float sm_max[8];
+  __shared__ float sm_part[8][kHeadDim + 4];
   const int bh = blockIdx.x;
   const int b = bh / num_heads;
   const int hq = bh % num_heads;
-  const int d = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int grp = tid >> 5;
+  const int ln = tid & 31;
   const int64_t base = static_cast<int64_t>(bh) * nsplit;
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(base + s) * 2]);
+
+  // global maximum over splits
+  float m = -INFINITY;
+  for (int s = tid; s < nsplit; s += 256) m = fmaxf(m, ws_ml[(base + s) * 2]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((tid & 63) == 0) sm_max[tid >> 6] = m;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(sm_max[0], sm_max[1]), fmaxf(sm_max[2], sm_max[3]));
   const float Mu = (M == -INFINITY) ? 0.f : M;
-  float val = 0.f, L = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float sc = fast_exp2(ws_ml[(base + s) * 2] - Mu);
-    val += sc * ws_o[(base + s) * kHeadDim + d];
-    L += sc * ws_ml[(base + s) * 2 + 1];
+
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float L = 0.f;
+#pragma unroll 4
+  for (int s = grp; s < nsplit; s += 8) {
+    const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (base + s) * 2);
+    const float4 v = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + 4 * ln);
+    const float sc = fast_exp2(ml.x - Mu);
+    acc.x += sc * v.x;
+    acc.y += sc * v.y;
+    acc.z += sc * v.z;
+    acc.w += sc * v.w;
+    L += sc * ml.y;
   }
-  const float r = L > 0.f ? val / L : 0.f;
-  o[static_cast<int64_t>(b) * o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
+  *reinterpret_cast<float4*>(&sm_part[grp][4 * ln]) = acc;
+  if (ln == 0) sm_part[grp][kHeadDim] = L;
+  __syncthreads();
+  if (tid < kHeadDim) {
+    float val = 0.f, Lt = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      val += sm_part[g][tid];
+      Lt += sm_part[g][kHeadDim];
+    }
+    const float r = Lt > 0.f ? val / Lt : 0.f;
+    o[static_cast<int64_t>(b) * o_stride0 + hq * kHeadDim + tid] = f32_to_bf16_bits(r);
+  }
 }
 
 template <int G, int U>
@@ -292,7 +330,7 @@ int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_attn launch: %s", hipGetErrorString(e));
   if (p.nsplit > 1) {
     hipLaunchKernelGGL(decode_merge_kernel, dim3(static_cast<unsigned>(p.batch) * p.num_heads),
-                       dim3(128), 0, stream, p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads,
+                       dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads,
                        p.nsplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_merge launch: %s", hipGetErrorString(e));

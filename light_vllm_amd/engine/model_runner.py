@@ -299,7 +299,7 @@ class ModelRunner:
         hq = hf.num_attention_heads // self.world_size
         hkv = hf.num_key_value_heads // self.world_size
         head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
-        need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks))
+        need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks, self.block_size))
                    for b in self.graph_bs)
         ops.reserve_decode_workspace(dev, need)
 

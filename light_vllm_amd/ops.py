@@ -111,8 +111,8 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
 _WORKSPACE: Dict[int, torch.Tensor] = {}
 
 
-def decode_num_splits(batch: int, num_kv_heads: int, max_blocks_per_seq: int) -> int:
-    return _lib.load().lv_decode_num_splits(batch, num_kv_heads, max_blocks_per_seq)
+def decode_num_splits(batch: int, num_kv_heads: int, max_blocks_per_seq: int, block_size: int = 256) -> int:
+    return _lib.load().lv_decode_num_splits(batch, num_kv_heads, max_blocks_per_seq, block_size)
 
 
 def decode_workspace_bytes(batch: int, num_heads: int, head_dim: int, num_splits: int) -> int:
@@ -172,7 +172,7 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     if B == 0:
         return out
     lib = _lib.load()
-    nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks)
+    nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks, block_size)
     ws_ptr, ws_bytes, keep = _workspace(dev, lib.lv_decode_workspace_bytes(B, Hq, D, nsplit))
     with torch.cuda.device(dev):
         rc = lib.lv_decode_attn(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),

@@ -38,10 +38,10 @@ def test_host_only_entry_points():
     assert lib.lv_decode_workspace_bytes(4, 32, 128, 1) == 0
     assert lib.lv_decode_workspace_bytes(4, 32, 128, 8) == 4 * 32 * 8 * 130 * 4
     assert lib.lv_decode_workspace_bytes(4, 32, 64, 8) == 0
-    assert lib.lv_decode_num_splits(256, 8, 4) == 1          # enough (sequence, kv head) units already
-    assert lib.lv_decode_num_splits(1, 1, 128) == 128         # one long sequence: split down to blocks
-    assert lib.lv_decode_num_splits(8, 8, 128) == 16
-    assert lib.lv_decode_num_splits(1, 8, 1) == 1
+    assert lib.lv_decode_num_splits(256, 8, 4, 256) == 1      # enough (sequence, kv head) units already
+    assert lib.lv_decode_num_splits(1, 1, 128, 256) == 512    # one long sequence: 64-token split units
+    assert lib.lv_decode_num_splits(8, 8, 128, 256) == 16
+    assert lib.lv_decode_num_splits(1, 8, 1, 256) == 4        # a single block still splits 4 ways
 
 
 def test_argument_validation_happens_before_any_launch():

@@ -55,7 +55,7 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False):
     tot = int(lens.sum())
     nb = int(((lens + BLOCK - 1) // BLOCK).sum())
     bytes_ = tot * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nb
-    ns = nsplit or ops.decode_num_splits(B, Hkv, bps)
+    ns = nsplit or ops.decode_num_splits(B, Hkv, bps, BLOCK)
     return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, us=round(t * 1e6, 1),
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
