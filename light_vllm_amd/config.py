@@ -28,6 +28,7 @@ class Config:
     device: str = "cuda"              # "cpu" only for plumbing tests that substitute the kernels
     strict_reference: bool = False    # BlockManager.can_append as the reference tests it
     random_seed: Optional[int] = None  # random-init weights (seeded) instead of loading `model`
+    random_on_device: bool = False    # benchmarks: draw the random weights on the GPU (fast, not portable)
     dist_init_method: str = "tcp://127.0.0.1:2333"
 
     def __post_init__(self):

@@ -47,7 +47,7 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); \
   st_acc[i] += st_now - st_prev; st_prev = st_now; }
 #define LV_STAMP_FLUSH if (g_lv_stamp_buf && lane == 0) { \
-  unsigned long long* d = g_lv_stamp_buf + ((static_cast<size_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 64 + wave * 8; \
+  unsigned long long* d = g_lv_stamp_buf + static_cast<size_t>(blockIdx.x) * 64 + wave * 8; \
   for (int i = 0; i < 8; ++i) d[i] = st_acc[i]; }
 #else
 #define LV_STAMP_DECL
@@ -76,15 +76,23 @@ void prefill_attn_kernel(const PrefillParams p) {
   // two buffers x (K tile | V tile)
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
 
-  const int b = blockIdx.z;
-  const int hq = blockIdx.y;
+  // 1-D grid, kv head fastest: workgroups are dealt round-robin over the 8 XCDs, so with 8 (or 4,
+  // 2, 1) kv heads all query tiles and query heads that read one (sequence, kv head)'s K/V run on
+  // one XCD and share its L2. Then query head within the group, then query tile (heaviest = last
+  // rows first), then sequence.
   const int G = p.num_heads / p.num_kv_heads;
-  const int kvh = hq / G;
+  int wg = blockIdx.x;
+  const int kvh = wg % p.num_kv_heads;
+  wg /= p.num_kv_heads;
+  const int hq = kvh * G + wg % G;
+  wg /= G;
+  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
+  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
+  const int b = wg / qtiles;
   const int q_start = p.cu_q[b];
   const int Lq = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
   const int Lk = p.cu_k[b + 1] - k_start;
-  const int q0 = (static_cast<int>(gridDim.x) - 1 - static_cast<int>(blockIdx.x)) * BM;
   if (q0 >= Lq) return;
   const int coff = Lk - Lq;  // causal offset: row r sees keys <= r + coff
 
@@ -108,6 +116,13 @@ void prefill_attn_kernel(const PrefillParams p) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[rb][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
+  // Retire the Q loads here, visibly to the compiler. Otherwise its wait-count bookkeeping carries
+  // them as "possibly outstanding" into the tile loop and guards every use of a Q fragment with a
+  // vmcnt wait that, in steady state, drains the K/V staging loads issued just before it.
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(qf[rb][s]));
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
@@ -367,14 +382,15 @@ void prefill_attn_kernel(const PrefillParams p) {
 template <bool PAGED, int NW, int RB>
 static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
   constexpr int BM = 32 * RB * NW;
-  const unsigned qtiles = static_cast<unsigned>((p.max_seqlen_q + BM - 1) / BM);
-  const dim3 grid(qtiles, static_cast<unsigned>(p.num_heads), static_cast<unsigned>(p.batch));
-  hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB>), grid, dim3(64 * NW), 0, stream, p);
+  const int64_t qtiles = (p.max_seqlen_q + BM - 1) / BM;
+  const int64_t total = qtiles * p.num_heads * p.batch;
+  hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB>), dim3(static_cast<unsigned>(total)), dim3(64 * NW), 0,
+                     stream, p);
 }
 
 int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
-  if (p.batch > 65535 || p.num_heads > 65535)
-    return fail(LV_ERR_UNSUPPORTED, "prefill: batch or num_heads > 65535");
+  if (static_cast<int64_t>((p.max_seqlen_q + 127) / 128) * p.num_heads * p.batch > INT32_MAX)
+    return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row.
   static const int force = getenv("LV_PREFILL_CFG") ? atoi(getenv("LV_PREFILL_CFG")) : -1;

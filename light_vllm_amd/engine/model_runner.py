@@ -29,7 +29,7 @@ from ..config import Config
 from ..layers.sampler import Sampler
 from ..models.qwen3 import Qwen3ForCausalLM
 from ..utils.context import get_context, reset_context, set_context
-from ..utils.loader import load_model, load_random
+from ..utils.loader import load_model, load_random, load_random_on_device
 from .sequence import Sequence
 
 _SHM_NAME = "lightvllm_amd"
@@ -68,7 +68,9 @@ class ModelRunner:
         torch.set_default_device(self.device)
         try:
             self.model = Qwen3ForCausalLM(hf_config)
-            if config.random_seed is not None:
+            if config.random_seed is not None and config.random_on_device:
+                load_random_on_device(self.model, config.random_seed)
+            elif config.random_seed is not None:
                 load_random(self.model, hf_config, config.random_seed)
             else:
                 load_model(self.model, config.model)

@@ -81,3 +81,17 @@ def load_random(model: nn.Module, hf_config, seed: int = 0, std: float = 0.02) -
         else:
             param = model.get_parameter(name)
             getattr(param, "weight_loader", default_weight_loader)(param, tensor)
+
+
+def load_random_on_device(model: nn.Module, seed: int = 0, std: float = 0.02) -> None:
+    """Fast random fill on the parameters' own device (benchmarks only: values differ between
+    devices and TP layouts, unlike load_random). Norm weights are set to one."""
+    dev_gens = {}
+    for name, param in model.named_parameters():
+        if name.endswith("norm.weight") or "layernorm" in name:
+            param.data.fill_(1.0)
+            continue
+        g = dev_gens.get(param.device)
+        if g is None:
+            g = dev_gens[param.device] = torch.Generator(device=param.device).manual_seed(seed)
+        param.data.normal_(0.0, std, generator=g)
