@@ -37,21 +37,32 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+// Ablation builds (-DLV_ABL=mask, tools/prefill_diag.hip) drop components while keeping their
+// inputs alive, to price them; results are then wrong by design. The shipped library has LV_ABL 0.
+// bits: 1 exp, 2 PV MFMA, 4 QK MFMA, 8 global loads, 16 LDS staging writes, 32 K LDS reads,
+// 64 V LDS reads, 128 softmax head (mask/max/rescale), 256 barriers, 512 output stores.
+#ifndef LV_ABL
+#define LV_ABL 0
+#endif
+#define LV_KEEP(x) asm volatile("" ::"v"(x))
+
 // Diagnostic builds (-DLV_STAMPS, tools/prefill_diag.hip) accumulate s_memtime deltas per loop
 // segment; the shipped library compiles these macros to nothing.
 #ifdef LV_STAMPS
 __device__ unsigned long long* g_lv_stamp_buf = nullptr;
-#define LV_STAMP_DECL unsigned long long st_prev, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+#define LV_STAMP_DECL unsigned long long st_prev, st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
   __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); __builtin_amdgcn_sched_barrier(0);
 #define LV_STAMP(i) { unsigned long long st_now; __builtin_amdgcn_sched_barrier(0); \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); \
   st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define LV_STAMP_COUNT st_acc[15] += 1;
 #define LV_STAMP_FLUSH if (g_lv_stamp_buf && lane == 0) { \
-  unsigned long long* d = g_lv_stamp_buf + static_cast<size_t>(blockIdx.x) * 64 + wave * 8; \
-  for (int i = 0; i < 8; ++i) d[i] = st_acc[i]; }
+  unsigned long long* d = g_lv_stamp_buf + static_cast<size_t>(blockIdx.x) * 128 + wave * 16; \
+  for (int i = 0; i < 16; ++i) d[i] = st_acc[i]; }
 #else
 #define LV_STAMP_DECL
 #define LV_STAMP(i)
+#define LV_STAMP_COUNT
 #define LV_STAMP_FLUSH
 #endif
 
@@ -63,18 +74,21 @@ struct IntC { static constexpr int value = V; };
 // P operand (same relative precision at any magnitude) absorb.
 constexpr float kDeferLog2 = 6.0f;
 
-// NW = waves per workgroup, RB = 32-row query blocks per wave; the workgroup's query tile is
+// NW = waves per workgroup, RB = 32-row query blocks per wave (1); the workgroup's query tile is
 // 32*RB*NW rows. Only RB = 1 is instantiated: with RB = 2 (each K/V fragment feeding two MFMAs,
 // one wave per SIMD) hipcc parks values in AGPRs and pays v_accvgpr_read/write copies around every
 // MFMA, which measured 30 % slower than RB = 1 at two waves per SIMD.
-template <bool PAGED, int NW, int RB>
+// DMA = true stages K/V tiles HBM -> LDS directly (global_load_lds, no VGPRs, no ds_write).
+template <bool PAGED, int NW, int RB, bool DMA>
 __global__ __launch_bounds__(64 * NW, (RB == 2 ? 1 : 2))
 void prefill_attn_kernel(const PrefillParams p) {
+  static_assert(RB == 1, "one 32-row block per wave");
   constexpr int BM = 32 * RB * NW;  // query rows per workgroup
   constexpr int NST = 16 / NW;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 4 * NW;     // tile rows between two chunks of one thread
   // two buffers x (K tile | V tile)
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
+  lds_byte* const lds3 = (lds_byte*)lds;
 
   // 1-D grid, kv head fastest: workgroups are dealt round-robin over the 8 XCDs, so with 8 (or 4,
   // 2, 1) kv heads all query tiles and query heads that read one (sequence, kv head)'s K/V run on
@@ -143,6 +157,7 @@ void prefill_attn_kernel(const PrefillParams p) {
 
   u32x4 kreg[NST], vreg[NST];
   auto stage_load = [&](int tile) {
+    if (LV_ABL & 8) return;
     const int kt0 = tile * BN;
     int64_t base_row;  // cache / packed row index of key kt0 (wave-uniform)
     if constexpr (PAGED) {
@@ -172,10 +187,44 @@ void prefill_attn_kernel(const PrefillParams p) {
   };
   auto stage_write = [&](auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
+    if (LV_ABL & 16) return;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       *reinterpret_cast<u32x4*>(lds + BUF * 2 * kTileBytes + 256 * RSTEP * i + st_lds) = kreg[i];
       *reinterpret_cast<u32x4*>(lds + BUF * 2 * kTileBytes + kTileBytes + 256 * RSTEP * i + st_lds) = vreg[i];
+    }
+  };
+  // LDS-DMA staging: one wave instruction moves a 1-KiB piece = 4 tile rows. Wave w moves pieces
+  // w + NW*i of K and of V. The LDS image of a piece is lane-linear (lane l -> row l>>4, physical
+  // chunk l&15), so the swizzle is applied to the per-lane SOURCE address: physical chunk c of
+  // row r must receive logical chunk c ^ x(r).
+  auto stage_dma = [&](int tile, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    if (LV_ABL & 8) return;
+    const int kt0 = tile * BN;
+    int64_t base_row;
+    if constexpr (PAGED) {
+      const int blk = bt_row[kt0 / p.block_size];
+      base_row = static_cast<int64_t>(blk) * p.block_size + (kt0 % p.block_size);
+    } else {
+      base_row = static_cast<int64_t>(k_start) + kt0;
+    }
+    const char* kb = reinterpret_cast<const char*>(p.k) + base_row * k_row_bytes;
+    const char* vb = reinterpret_cast<const char*>(p.v) + base_row * v_row_bytes;
+    const int last = Lk - 1 - kt0;
+    const int lrow = lane >> 4;                                   // row inside the piece
+    const int lchunk = (lane & 15) ^ ((lrow << 2) | (wave & 3));  // x(r): r&3 = lrow, (r>>2)&3 = wave&3
+    const uint32_t colb = static_cast<uint32_t>(kvh * kHeadDim + 8 * lchunk) * 2u;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int piece = wave + NW * i;
+      const uint32_t r = static_cast<uint32_t>(min(4 * piece + lrow, last));
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(kb + r * k_row_bytes + colb),
+          (__attribute__((address_space(3))) void*)(lds3 + BUF * 2 * kTileBytes + 1024 * piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(vb + r * v_row_bytes + colb),
+          (__attribute__((address_space(3))) void*)(lds3 + BUF * 2 * kTileBytes + kTileBytes + 1024 * piece), 16, 0, 0);
     }
   };
 
@@ -198,7 +247,6 @@ void prefill_attn_kernel(const PrefillParams p) {
   //   K as A operand: row c of a 32-key sub-tile, chunk (2s+h) swizzled with the row   -> 8 bases
   //   V^T as A operand (ds_read_b64_tr_b16, per 16-lane group): lane 4q+p of group gi addresses
   //   row 8*second + 4*(gi>>1) + q, columns 32*dt + 16*(gi&1) + 4p .. +3                 -> 8 bases
-  lds_byte* const lds3 = (lds_byte*)lds;
   const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
   const int gi = lane >> 4;
   const int tq = (lane & 15) >> 2;
@@ -218,142 +266,223 @@ void prefill_attn_kernel(const PrefillParams p) {
 
   LV_STAMP_DECL
 
-  // ---- pieces of one 32-key online-softmax step for row block rb
+  // ---- pieces of one 32-key online-softmax step (row block 0; RB == 1)
+  auto load_ka = [&](bf16x8 (&ka)[8], int byte_off) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      ka[s] = (LV_ABL & 32) ? qf[0][s]
+                            : *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kaddr[s] + byte_off);
+  };
+  auto load_va = [&](bf16x8 (&va)[2][4], int byte_off) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int second = 0; second < 2; ++second) {
+          bf16x4 t;
+          if (LV_ABL & 64) { t[0] = qf[0][dt][0]; t[1] = qf[0][dt][1]; t[2] = qf[0][s][2]; t[3] = qf[0][second][3]; }
+          else t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(vaddr[dt][second] + byte_off + 4096 * s));
+          va[s][dt][4 * second + 0] = t[0];
+          va[s][dt][4 * second + 1] = t[1];
+          va[s][dt][4 * second + 2] = t[2];
+          va[s][dt][4 * second + 3] = t[3];
+        }
+  };
   // S^T = K Q^T
-  auto qk = [&](const bf16x8 (&ka)[8], int rb, f32x16& sacc) {
+  auto qk = [&](const bf16x8 (&ka)[8], f32x16& sacc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[rb][s], sacc, 0, 0, 0);
+    for (int s = 0; s < 8; ++s) {
+      if (LV_ABL & 4) { LV_KEEP(ka[s]); continue; }
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[0][s], sacc, 0, 0, 0);
+    }
   };
-  // causal mask, row maximum and (rarely) rescale of the running state; returns max * scale*log2e
-  auto softmax_head = [&](int ks0, int rb, f32x16& sacc) -> float {
-    if (ks0 + 31 > wrow0 + 32 * rb + coff) {  // only sub-tiles that reach past the block's first row limit
+  // causal mask + row maximum of one step; returns the row maximum (all 64 lanes)
+  auto row_max = [&](int ks0, f32x16& sacc) -> float {
+    if (ks0 + 31 > wrow0 + coff) {  // only steps that reach past the wave's first row limit
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = ks0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (key > my_lim[rb]) sacc[r] = -INFINITY;
+        if (key > my_lim[0]) sacc[r] = -INFINITY;
       }
     }
     float mx = sacc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-    {
-      // exchange with lane ^ 32 on the VALU (v_permlane32_swap): no LDS round trip
-      const unsigned mb = __builtin_bit_cast(unsigned, mx);
-      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
-    // Rescale only when some row of the wave outgrows its running maximum by more than the
-    // deferral threshold (always true on a row's first visible keys: m_run = -inf).
-    if (__builtin_amdgcn_ballot_w64(mx - m_run[rb] > defer_raw) != 0) {
-      const float m_new = fmaxf(m_run[rb], mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run[rb] - m_use) * cexp);
-      m_run[rb] = m_new;
-      l_run[rb] *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[rb][dt][r] *= alpha;
-    }
-    return ((m_run[rb] == -INFINITY) ? 0.f : m_run[rb]) * cexp;
+    // exchange with lane ^ 32 on the VALU (v_permlane32_swap): no LDS round trip
+    const unsigned mb = __builtin_bit_cast(unsigned, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
   };
-  // P = exp2(S*c - m*c), row-sum share, bf16 P fragments (the B operand of O^T += V^T P^T)
-  auto softmax_tail = [&](int rb, const f32x16& sacc, float mc, bf16x8 (&pf)[2]) {
+  // Running-max update. The accumulator is rescaled only when some row of the wave outgrows its
+  // running maximum by more than the deferral threshold (always on a row's first visible keys,
+  // m_run = -inf). Returns the factor for O and l (1 when nothing changes) through `alpha`.
+  auto need_rescale = [&](float mx) -> bool {
+    if (LV_ABL & 128) return false;
+    return __builtin_amdgcn_ballot_w64(mx - m_run[0] > defer_raw) != 0;
+  };
+  auto new_max = [&](float mx) -> float {  // updates m_run, returns alpha
+    const float m_new = fmaxf(m_run[0], mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run[0] - m_use) * cexp);
+    m_run[0] = m_new;
+    return alpha;
+  };
+  auto rescale = [&](float alpha) {
+    l_run[0] *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[0][dt][r] *= alpha;
+  };
+  // P = exp2(S*c - m*c) against the current running max, bf16 P fragments (B operand of
+  // O^T += V^T P^T); returns this lane's share of the row sum
+  auto softmax_tail = [&](const f32x16& sacc, bf16x8 (&pf)[2]) -> float {
+    const float mc = ((m_run[0] == -INFINITY) ? 0.f : m_run[0]) * cexp;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
+      const float pe = (LV_ABL & 1) ? fmaf(sacc[r], cexp, -mc) : __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
       psum += pe;
       pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
     }
-    l_run[rb] += psum;
+    return psum;
   };
-  auto pv = [&](const bf16x8 (&va)[2][4], int rb, const bf16x8 (&pf)[2]) {
+  auto pv = [&](const bf16x8 (&va)[2][4], const bf16x8 (&pf)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        oacc[rb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pf[s], oacc[rb][dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) {
+        if (LV_ABL & 2) { LV_KEEP(va[s][dt]); LV_KEEP(pf[s]); continue; }
+        oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[s][dt], pf[s], oacc[0][dt], 0, 0, 0);
+      }
   };
+  // Scheduling hint for a region holding 8 MFMAs and a block of vector work: one MFMA, then PER
+  // vector instructions, eight times, so the vector work issues in the MFMAs' shadow.
+  auto interleave8 = [&](auto per_c) {
+    constexpr int PER = decltype(per_c)::value;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);      // plain vector ALU
+      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);        // transcendental (v_exp_f32)
+    }
+  };
+
+  // One 64-key tile = two 32-key online-softmax steps A and B, software pipelined inside the
+  // wave so that matrix and vector work of different steps can issue together:
+  //   QK(A) | max(A) | [QK(B) with exp(A)] | max(B) | [PV(A) with exp(B)] | rescale(B)? | PV(B)
+  // A step's P is exponentiated against the running max in force when its max was taken; the
+  // accumulator rescale that step B may ask for is applied after PV(A) has been added (PV(A) was
+  // formed at the old scale) and before PV(B).
   auto compute = [&](int tile, auto buf_c) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr int kBufOff = BUF * 2 * kTileBytes;
     const int kt0 = tile * BN;
     // waves whose rows all lie above this tile have nothing to add
-    if (kt0 > wrow0 + 32 * RB - 1 + coff) return;
+    if (kt0 > wrow0 + 31 + coff) return;
+    LV_STAMP_COUNT
 
-    // The 64-key tile is consumed as two 32-key online-softmax steps, which keeps S at 16
-    // registers per row block and leaves room to fetch every MFMA operand of a step early.
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int ks0 = kt0 + 32 * sub;
-      // K rows of this sub-tile (A operand of S^T = K Q^T), all 8 k-steps in flight at once
-      bf16x8 ka[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        ka[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kaddr[s] + kBufOff + 8192 * sub);
-      f32x16 sacc[RB];
-      bf16x8 pf[RB][2];
-      qk(ka, 0, sacc[0]);
-      if constexpr (RB == 1) __builtin_amdgcn_sched_barrier(0);  // K fragments dead; V fragments reuse their registers
+    bf16x8 kx[8];       // K fragments of A, then of B
+    bf16x8 va[2][4];    // V^T fragments of A
+    bf16x8 vb[2][4];    // V^T fragments of B
+    bf16x8 pa[2], pb[2];
+    f32x16 sa, sb;
 
-      // V^T fragments of this sub-tile (A operand of O^T += V^T P^T): issued now, consumed after
-      // the softmax below, so their LDS latency hides under it.
-      bf16x8 va[2][4];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int second = 0; second < 2; ++second) {
-            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(
-                    vaddr[dt][second] + kBufOff + 256 * (32 * sub + 16 * s)));
-            va[s][dt][4 * second + 0] = t[0];
-            va[s][dt][4 * second + 1] = t[1];
-            va[s][dt][4 * second + 2] = t[2];
-            va[s][dt][4 * second + 3] = t[3];
-          }
-      LV_STAMP(4)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        if (rb > 0) qk(ka, rb, sacc[rb]);
-        const float mc = softmax_head(ks0, rb, sacc[rb]);
-        softmax_tail(rb, sacc[rb], mc, pf[rb]);
-      }
-      LV_STAMP(5)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) pv(va, rb, pf[rb]);
-      LV_STAMP(6)
-    }
+    load_ka(kx, kBufOff);
+    qk(kx, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    load_ka(kx, kBufOff + 8192);
+    load_va(va, kBufOff);
+    LV_STAMP(4)
+    const float mxa = row_max(kt0, sa);
+    if (need_rescale(mxa)) rescale(new_max(mxa));
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(8)
+    // ---- region 1: S_B = K_B Q^T  with  P_A = exp(S_A)
+    qk(kx, sb);
+    const float psa = softmax_tail(sa, pa);
+    // pin the vector work inside this region (pure arithmetic would otherwise sink to its users)
+    asm volatile("" ::"v"(pa[0]), "v"(pa[1]), "v"(psa));
+    interleave8(IntC<5>{});
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(9)
+    l_run[0] += psa;
+    load_va(vb, kBufOff + 8192);
+    const float mxb = row_max(kt0 + 32, sb);
+    const bool nb = need_rescale(mxb);
+    float alpha_b = 1.f;
+    if (nb) alpha_b = new_max(mxb);
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(10)
+    // ---- region 2: O += V_A^T P_A  with  P_B = exp(S_B)
+    pv(va, pa);
+    const float psb = softmax_tail(sb, pb);
+    asm volatile("" ::"v"(pb[0]), "v"(pb[1]), "v"(psb));
+    interleave8(IntC<5>{});
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(5)
+    if (nb) rescale(alpha_b);
+    l_run[0] += psb;
+    // ---- region 3: O += V_B^T P_B
+    pv(vb, pb);
+    LV_STAMP(6)
   };
 
-  // ---- main loop: tile t is computed from buffer t&1 while tile t+1 sits in registers and tile
-  // t+2's loads are in flight; one workgroup barrier per tile.
-  if (ntiles > 0) {
-    stage_load(0);
-    stage_write(IntC<0>{});
-    __syncthreads();
-    if (ntiles > 1) stage_load(1);
-  }
-  for (int tile = 0; tile < ntiles; tile += 2) {
-    LV_STAMP(3)
-    compute(tile, IntC<0>{});
-    if (tile + 1 < ntiles) stage_write(IntC<1>{});
-    LV_STAMP(1)
-    __syncthreads();
-    LV_STAMP(0)
-    if (tile + 2 < ntiles) stage_load(tile + 2);
-    if (tile + 1 < ntiles) {
-      LV_STAMP(3)
-      compute(tile + 1, IntC<1>{});
-      if (tile + 2 < ntiles) stage_write(IntC<0>{});
-      LV_STAMP(1)
+  // ---- main loop, LDS-DMA staging: tile t+1 is copied into the other buffer while tile t is
+  // computed; the barrier at the end of the interval (its fence waits for the copies) publishes it.
+  if constexpr (DMA) {
+    if (ntiles > 0) {
+      stage_dma(0, IntC<0>{});
       __syncthreads();
+    }
+    for (int tile = 0; tile < ntiles; tile += 2) {
+      if (tile + 1 < ntiles) stage_dma(tile + 1, IntC<1>{});
+      LV_STAMP(3)
+      compute(tile, IntC<0>{});
+      LV_STAMP(1)
+      if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
-      if (tile + 3 < ntiles) stage_load(tile + 3);
+      if (tile + 1 < ntiles) {
+        if (tile + 2 < ntiles) stage_dma(tile + 2, IntC<0>{});
+        LV_STAMP(3)
+        compute(tile + 1, IntC<1>{});
+        LV_STAMP(1)
+        if (!(LV_ABL & 256)) __syncthreads();
+        LV_STAMP(0)
+      }
+    }
+  } else {
+  // ---- main loop: tile t is computed from buffer t&1 while tile t+1 sits in registers and tile
+    // t+2's loads are in flight; one workgroup barrier per tile.
+    if (ntiles > 0) {
+      stage_load(0);
+      stage_write(IntC<0>{});
+      __syncthreads();
+      if (ntiles > 1) stage_load(1);
+    }
+    for (int tile = 0; tile < ntiles; tile += 2) {
+      compute(tile, IntC<0>{});
+      if (tile + 1 < ntiles) stage_write(IntC<1>{});
+      LV_STAMP(1)
+      // the next loads are issued before the barrier: a wave that gets here early spends its
+      // wait issuing them, instead of all waves queueing on the memory pipe right after it
+      if (tile + 2 < ntiles) stage_load(tile + 2);
+      LV_STAMP(3)
+      if (!(LV_ABL & 256)) __syncthreads();
+      LV_STAMP(0)
+      if (tile + 1 < ntiles) {
+        compute(tile + 1, IntC<1>{});
+        if (tile + 2 < ntiles) stage_write(IntC<0>{});
+        LV_STAMP(1)
+        if (tile + 3 < ntiles) stage_load(tile + 3);
+        LV_STAMP(3)
+        if (!(LV_ABL & 256)) __syncthreads();
+        LV_STAMP(0)
+      }
     }
   }
   LV_STAMP_FLUSH
@@ -364,7 +493,7 @@ void prefill_attn_kernel(const PrefillParams p) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int my_row = wrow0 + 32 * rb + c;
-    if (my_row < Lq) {
+    if (my_row < Lq && !(LV_ABL & 512)) {
       uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -379,12 +508,12 @@ void prefill_attn_kernel(const PrefillParams p) {
   }
 }
 
-template <bool PAGED, int NW, int RB>
+template <bool PAGED, int NW, int RB, bool DMA>
 static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
   constexpr int BM = 32 * RB * NW;
   const int64_t qtiles = (p.max_seqlen_q + BM - 1) / BM;
   const int64_t total = qtiles * p.num_heads * p.batch;
-  hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB>), dim3(static_cast<unsigned>(total)), dim3(64 * NW), 0,
+  hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB, DMA>), dim3(static_cast<unsigned>(total)), dim3(64 * NW), 0,
                      stream, p);
 }
 
@@ -395,10 +524,13 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row.
   static const int force = getenv("LV_PREFILL_CFG") ? atoi(getenv("LV_PREFILL_CFG")) : -1;
   const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 1024 ? 1 : 0);
+  static const int dma = getenv("LV_PREFILL_DMA") ? atoi(getenv("LV_PREFILL_DMA")) : 0;
   if (p.block_table) {
-    if (cfg == 1) launch_cfg<true, 8, 1>(p, stream); else launch_cfg<true, 4, 1>(p, stream);
+    if (cfg == 1) { if (dma) launch_cfg<true, 8, 1, true>(p, stream); else launch_cfg<true, 8, 1, false>(p, stream); }
+    else { if (dma) launch_cfg<true, 4, 1, true>(p, stream); else launch_cfg<true, 4, 1, false>(p, stream); }
   } else {
-    if (cfg == 1) launch_cfg<false, 8, 1>(p, stream); else launch_cfg<false, 4, 1>(p, stream);
+    if (cfg == 1) { if (dma) launch_cfg<false, 8, 1, true>(p, stream); else launch_cfg<false, 8, 1, false>(p, stream); }
+    else { if (dma) launch_cfg<false, 4, 1, true>(p, stream); else launch_cfg<false, 4, 1, false>(p, stream); }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "prefill_attn launch: %s", hipGetErrorString(e));

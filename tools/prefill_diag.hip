@@ -7,7 +7,7 @@
 #include <string.h>
 #include <vector>
 
-#include "../light_vllm_amd/csrc/prefill_attn.hip"
+#include "../light_vllm_amd/csrc/prefill_attn.hip"  // defines LV_ABL (0 unless -DLV_ABL=n)
 
 namespace lv {
 int fail(int code, const char* fmt, ...) {
@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dv, hv.data(), nk * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dcu, cu.data(), (B + 1) * 4, hipMemcpyHostToDevice));
   const int qtiles = (L + 127) / 128;
-  const size_t nst = (size_t)B * Hq * qtiles * 64;
+  const size_t nst = (size_t)B * Hq * qtiles * 128;
   CK(hipMalloc(&dst, nst * 8)); CK(hipMemset(dst, 0, nst * 8));
 #ifdef LV_STAMPS
   CK(hipMemcpyToSymbol(HIP_SYMBOL(lv::g_lv_stamp_buf), &dst, sizeof(dst)));
@@ -67,11 +67,14 @@ int main(int argc, char** argv) {
 #endif
   std::vector<unsigned long long> st(nst);
   CK(hipMemcpy(st.data(), dst, nst * 8, hipMemcpyDeviceToHost));
-  double seg[8] = {0}; double tot = 0;
-  for (size_t i = 0; i < nst; ++i) { seg[i % 8] += (double)st[i]; tot += (double)st[i]; }
-  const char* names[8] = {"barrier A (wait readers)", "ds_write stage", "barrier B", "issue next loads",
-                          "QK^T (LDS reads + 16 MFMA)", "mask + softmax", "PV (tr reads + 16 MFMA)", "-"};
-  for (int i = 0; i < 7; ++i) printf("%-30s %6.2f %%\n", names[i], 100.0 * seg[i] / tot);
-  const double tiles = 0; (void)tiles;
+  double seg[16] = {0}; double tot = 0;
+  for (size_t i = 0; i < nst; ++i) { seg[i % 16] += (double)st[i]; tot += (double)st[i]; }
+  const char* names[16] = {"barrier (wait for all waves)", "ds_write stage", "-", "issue next tile's loads",
+                           "K_A reads, QK_A, K_B+V_A reads", "region 2: PV_A | exp(B)", "PV_B", "-",
+                           "max(A) (+rescale)", "region 1: QK_B | exp(A)", "V_B reads issue, max(B)", "-", "-", "-", "-", "-"};
+  tot -= seg[15];
+  for (int i = 0; i < 15; ++i)
+    if (seg[i] > 0) printf("%-34s %6.2f %%   %8.0f ticks per (wave, tile)\n", names[i], 100.0 * seg[i] / tot, seg[i] / seg[15]);
+  printf("total %.0f ticks per (wave, tile); %.0f (wave, tile) units\n", tot / seg[15], seg[15]);
   return 0;
 }
