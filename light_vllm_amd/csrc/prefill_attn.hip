@@ -508,6 +508,403 @@ void prefill_attn_kernel(const PrefillParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Phase-locked variant for long prompts: 8 waves x 32 rows, two wave groups (waves 0-3, 4-7; wave
+// w and w+4 share a SIMD) that run the same four-cluster program per K/V tile one cluster apart,
+// so each SIMD always has one wave in a matrix cluster beside its partner in a load cluster:
+//
+//   L_K(i)  read the K(i+1) fragments, second half of exp for tile i, apply a pending
+//           accumulator rescale
+//   C_QK(i) S(i+1) = K(i+1) Q^T                                  (16 MFMAs, operands in registers)
+//   L_V(i)  publish K(i+2) and V(i+1) to LDS, issue the global loads of K(i+3) and V(i+2), read
+//           three quarters of the V(i) fragments, mask / row maximum / rescale decision of tile i+1
+//   C_PV(i) O += V(i)^T P(i)  beside the first half of exp for tile i+1          (16 MFMAs)
+//
+// One workgroup barrier closes every cluster. The softmax of a tile is spread over three
+// clusters, so the P of tile i and the scores of tile i+1 are live together (two named register
+// sets, alternating with the tile parity). A rescale decided for tile i+1 while P(i) is still
+// to be added is applied to l at once and to O in the next L_K, after O += V(i)^T P(i).
+#ifndef LV_PP_LPRIO
+#define LV_PP_LPRIO 2
+#endif
+template <bool PAGED>
+__global__ __launch_bounds__(512, 2)
+void prefill_pp_kernel(const PrefillParams p) {
+  constexpr int NW = 8;
+  constexpr int BM = 32 * NW;
+  constexpr int NST = 2;      // 16-byte chunks of K (and of V) each thread stages per tile
+  constexpr int RSTEP = 32;   // tile rows between them
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];  // slot s: K at 2s, V at 2s+1
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  const int G = p.num_heads / p.num_kv_heads;
+  int wg = blockIdx.x;
+  const int kvh = wg % p.num_kv_heads;
+  wg /= p.num_kv_heads;
+  const int hq = kvh * G + wg % G;
+  wg /= G;
+  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
+  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
+  const int b = wg / qtiles;
+  const int q_start = p.cu_q[b];
+  const int Lq = p.cu_q[b + 1] - q_start;
+  const int k_start = p.cu_k[b];
+  const int Lk = p.cu_k[b + 1] - k_start;
+  if (q0 >= Lq) return;
+  const int coff = Lk - Lq;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int lane = tid & 63;
+  const int h = lane >> 5;
+  const int c = lane & 31;
+  const int wrow0 = q0 + wave * 32;
+  const int my_row = wrow0 + c;
+  const int my_lim = my_row + coff;
+
+  bf16x8 qf[8];
+  {
+    const int row_ld = min(my_row, Lq - 1);
+    const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(qf[s]));
+  }
+
+  const int last_row = min(q0 + BM - 1, Lq - 1);
+  const int max_key = min(last_row + coff, Lk - 1);
+  const int ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
+
+  // ---- staging (register path): chunk st_ch of tile rows st_r and st_r + 32
+  const int st_ch = tid & 15;
+  const int st_r = tid >> 4;
+  const int32_t* bt_row = PAGED ? p.block_table + static_cast<int64_t>(b) * p.bt_stride : nullptr;
+  const uint32_t k_row_bytes = static_cast<uint32_t>(p.k_stride0) * 2u;
+  const uint32_t v_row_bytes = static_cast<uint32_t>(p.v_stride0) * 2u;
+  const uint32_t col_bytes = static_cast<uint32_t>(kvh * kHeadDim + 8 * st_ch) * 2u;
+  const int st_lds = lds_off(st_r, st_ch);
+
+  u32x4 kreg[NST], vreg[NST];
+  auto tile_row = [&](int tile) -> int64_t {  // cache / packed row of the tile's first key
+    const int kt0 = tile * BN;
+    if constexpr (PAGED) {
+      const int blk = bt_row[kt0 / p.block_size];
+      return static_cast<int64_t>(blk) * p.block_size + (kt0 % p.block_size);
+    } else {
+      return static_cast<int64_t>(k_start) + kt0;
+    }
+  };
+  auto load_rows = [&](int tile, const uint16_t* base, uint32_t row_bytes, u32x4 (&reg)[NST]) {
+    if (tile >= ntiles) return;
+    const char* tb = reinterpret_cast<const char*>(base) + tile_row(tile) * row_bytes + col_bytes;
+    const int last = Lk - 1 - tile * BN;  // rows past the sequence end re-read its last row (masked later)
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const uint32_t r = static_cast<uint32_t>(min(st_r + RSTEP * i, last));
+      reg[i] = *reinterpret_cast<const u32x4*>(tb + r * row_bytes);
+    }
+  };
+  auto write_rows = [&](int byte_off, const u32x4 (&reg)[NST]) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      *reinterpret_cast<u32x4*>(lds + byte_off + 256 * RSTEP * i + st_lds) = reg[i];
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  float pend_alpha = 1.f;
+  bool pend = false;
+  const float cexp = p.scale_log2e;
+  const float defer_raw = kDeferLog2 / cexp;
+
+  // LDS read addresses inside slot 0. The swizzled fragment addresses of prefill_attn_kernel
+  // differ from one per-lane base only by XOR with compile-time constants:
+  //   K, d-step s:                 kbase ^ 32 s
+  //   V^T, column block dt, rows +8 ("second"):   vbase ^ 64 dt ^ (second ? 2048 | 32 : 0)
+  // so two registers stand in for sixteen; the XORs are redone where the reads are issued.
+  const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
+  const int gi = lane >> 4;
+  const int tq = (lane & 15) >> 2;
+  const int tp = lane & 3;
+  const int kbase0 = (256 * c) | (16 * (h ^ xr));
+  const int vbase0 = kTileBytes + lds_off(4 * (gi >> 1) + tq, 2 * (gi & 1) + (tp >> 1)) + 8 * (tp & 1);
+
+  // K fragments of four d-steps (s0 .. s0+3) of a 32-key half
+  auto load_kg = [&](bf16x8 (&kg)[4], int kbase, int byte_off, auto s0_c) {
+    constexpr int S0 = decltype(s0_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      kg[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds3 + (kbase ^ (32 * (S0 + j))) + byte_off);
+  };
+  // V^T fragments of one 32-column block dt for the tile's four 16-key steps (index 2*half + s)
+  auto load_vg = [&](bf16x8 (&vg)[4], int vbase, int byte_off, auto dt_c) {
+    constexpr int DT = decltype(dt_c)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int second = 0; second < 2; ++second) {
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(lds3 + (vbase ^ (64 * DT) ^ (second * (2048 | 32))) + byte_off + 4096 * ks));
+        vg[ks][4 * second + 0] = t[0];
+        vg[ks][4 * second + 1] = t[1];
+        vg[ks][4 * second + 2] = t[2];
+        vg[ks][4 * second + 3] = t[3];
+      }
+  };
+  auto qk4 = [&](const bf16x8 (&kg)[4], f32x16& sacc, auto s0_c) {
+    constexpr int S0 = decltype(s0_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg[j], qf[S0 + j], sacc, 0, 0, 0);
+  };
+  auto pv4 = [&](const bf16x8 (&vg)[4], const bf16x8 (&pf)[2][2], auto dt_c) {
+    constexpr int DT = decltype(dt_c)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      oacc[DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vg[ks], pf[ks >> 1][ks & 1], oacc[DT], 0, 0, 0);
+  };
+  // scheduling hint: N x {1 MFMA, 3 vector ALU, 1 transcendental}
+  auto mix = [&](auto n_c) {
+#pragma unroll
+    for (int g = 0; g < decltype(n_c)::value; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+    }
+  };
+  // mask, row maximum and rescale decision of the tile whose scores are (sa, sb)
+  auto head = [&](int tile, f32x16& sa, f32x16& sb) {
+    const int kt0 = tile * BN;
+    if (LV_ABL & 128) { if (tile == 0) m_run = 0.f; return; }
+    if (kt0 + 63 > wrow0 + coff) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (key > my_lim) sa[r] = -INFINITY;
+        if (key + 32 > my_lim) sb[r] = -INFINITY;
+      }
+    }
+    float mx = fmaxf(sa[0], sb[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
+    const unsigned mb = __builtin_bit_cast(unsigned, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    if (__builtin_amdgcn_ballot_w64(mx - m_run > defer_raw) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * cexp);
+      m_run = m_new;
+      l_run *= alpha;       // every P summed so far is at the old scale
+      pend_alpha = alpha;   // O follows once the P still at the old scale has been added
+      pend = true;
+    }
+  };
+  auto tail = [&](const f32x16& sacc, bf16x8 (&pf)[2]) -> float {
+    const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
+      psum += pe;
+      pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
+    }
+    return psum;
+  };
+
+  LV_STAMP_DECL
+  f32x16 S[2][2];      // [tile parity][32-key half] scores
+  bf16x8 P[2][2][2];   // [tile parity][32-key half][k-step] probabilities
+
+  // One tile interval. PAR = parity of tile i; CUR: tile i exists (i >= 0); NEXT: tile i+1 exists.
+  // a quarter of a 32-key half's exp: P = exp2(S*c - m*c) for registers 4q .. 4q+3
+  auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float mc, float& psum, auto q_c) {
+    constexpr int Q = decltype(q_c)::value;
+#pragma unroll
+    for (int r = 4 * Q; r < 4 * Q + 4; ++r) {
+      const float pe = (LV_ABL & 1) ? fmaf(sacc[r], cexp, -mc) : __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
+      psum += pe;
+      pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
+    }
+  };
+  // scheduling hint for a slice of 4 MFMAs beside a quarter of exp work
+  auto mix4 = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+    }
+  };
+
+  auto body = [&](int i, auto par_c, auto cur_c, auto next_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int NPAR = PAR ^ 1;
+    constexpr bool CUR = decltype(cur_c)::value != 0;
+    constexpr bool NEXT = decltype(next_c)::value != 0;
+    int kbase = kbase0, vbase = vbase0;   // opaque copies: keeps the XORs next to the reads
+    asm volatile("" : "+v"(kbase), "+v"(vbase));
+    LV_STAMP_COUNT
+    bf16x8 kx[4][4];   // K fragments: [32-key half * 2 + d-step group][4]
+    bf16x8 vx[3][4];   // V^T fragments: [column block][16-key step]; block 3 reuses block 0's registers
+    // ---- L_K(i)
+    __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
+    LV_STAMP(10)
+    if constexpr (NEXT) {
+      load_kg(kx[0], kbase, NPAR * 2 * kTileBytes, IntC<0>{});
+      load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
+      load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
+      load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
+    }
+    LV_STAMP(11)
+    if constexpr (CUR) {
+      if (pend) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= pend_alpha;
+        pend = false;
+      }
+      // second half of exp for tile i, while the K reads are in flight
+      const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
+      float ps = 0.f;
+      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<0>{});
+      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<1>{});
+      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<2>{});
+      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<3>{});
+      l_run += ps;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(0)
+    __syncthreads();
+    LV_STAMP(4)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (NEXT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[NPAR][0][r] = 0.f; S[NPAR][1][r] = 0.f; }
+      qk4(kx[0], S[NPAR][0], IntC<0>{});
+      qk4(kx[1], S[NPAR][0], IntC<4>{});
+      qk4(kx[2], S[NPAR][1], IntC<0>{});
+      qk4(kx[3], S[NPAR][1], IntC<4>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(1)
+    __syncthreads();
+    LV_STAMP(5)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L_V(i)
+    __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
+    // All staging sits here, so every global load has a whole tile interval to land and the
+    // wait in front of the LDS writes is exact. Slots: K(i+2) replaces K(i), last read in
+    // C_QK(i-1); V(i+1) replaces V(i-1), last read in C_PV(i-1), one cluster before the second
+    // group gets here.
+    if constexpr (NEXT) {
+      if (i + 1 < ntiles) {
+        write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);   // V(i+1)
+        if (i + 2 < ntiles) write_rows(PAR * 2 * kTileBytes, kreg);   // K(i+2)
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(i + 2, p.v, v_row_bytes, vreg);
+        load_rows(i + 3, p.k, k_row_bytes, kreg);
+      }
+    }
+    LV_STAMP(8)
+    if constexpr (CUR) {
+      load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<0>{});
+      load_vg(vx[1], vbase, PAR * 2 * kTileBytes, IntC<1>{});
+      load_vg(vx[2], vbase, PAR * 2 * kTileBytes, IntC<2>{});
+    }
+    LV_STAMP(9)
+    if constexpr (NEXT) head(i + 1, S[NPAR][0], S[NPAR][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(2)
+    __syncthreads();
+    LV_STAMP(6)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C_PV(i): O += V(i)^T P(i) beside the first half of exp for tile i+1
+    __builtin_amdgcn_s_setprio(0);
+    {
+      const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
+      float ps = 0.f;
+      if constexpr (CUR) pv4(vx[0], P[PAR], IntC<0>{});
+      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<0>{});
+      if constexpr (CUR && NEXT) mix4();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CUR) load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<3>{});
+      if constexpr (CUR) pv4(vx[1], P[PAR], IntC<1>{});
+      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<1>{});
+      if constexpr (CUR && NEXT) mix4();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CUR) pv4(vx[2], P[PAR], IntC<2>{});
+      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<2>{});
+      if constexpr (CUR && NEXT) mix4();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CUR) pv4(vx[0], P[PAR], IntC<3>{});
+      if constexpr (NEXT) {
+        tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<3>{});
+        l_run += ps;
+      }
+      if constexpr (CUR && NEXT) mix4();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LV_STAMP(3)
+    __syncthreads();
+    LV_STAMP(7)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (ntiles > 0) {
+    // prologue: K(0) published, K(1) and V(0) in flight
+    load_rows(0, p.k, k_row_bytes, kreg);
+    write_rows(0, kreg);
+    load_rows(1, p.k, k_row_bytes, kreg);
+    load_rows(0, p.v, v_row_bytes, vreg);
+    __syncthreads();
+    if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
+    body(-1, IntC<1>{}, IntC<0>{}, IntC<1>{});
+    // Every interval also forms the scores of tile i+1; past the last tile they are computed from
+    // stale LDS and fully masked (every key of tile ntiles lies beyond every row's causal limit),
+    // which leaves the running statistics untouched and keeps the loop body free of branches
+    // around its matrix clusters.
+    for (int i = 0; i < ntiles; i += 2) {
+      body(i, IntC<0>{}, IntC<1>{}, IntC<1>{});
+      if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{}, IntC<1>{});
+    }
+    if (grp == 0) __syncthreads();
+  }
+  LV_STAMP_FLUSH
+
+  // ---- epilogue
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+  if (my_row < Lq) {
+    uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u32x2 w;
+        w[0] = pack_bf16x2(oacc[dt][4 * rg + 0] * inv, oacc[dt][4 * rg + 1] * inv);
+        w[1] = pack_bf16x2(oacc[dt][4 * rg + 2] * inv, oacc[dt][4 * rg + 3] * inv);
+        *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * rg) = w;
+      }
+  }
+}
+
+template <bool PAGED>
+static void launch_pp(const PrefillParams& p, hipStream_t stream) {
+  const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
+  const int64_t total = qtiles * p.num_heads * p.batch;
+  hipLaunchKernelGGL((prefill_pp_kernel<PAGED>), dim3(static_cast<unsigned>(total)), dim3(512), 0, stream, p);
+}
+
 template <bool PAGED, int NW, int RB, bool DMA>
 static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
   constexpr int BM = 32 * RB * NW;
@@ -525,7 +922,9 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   static const int force = getenv("LV_PREFILL_CFG") ? atoi(getenv("LV_PREFILL_CFG")) : -1;
   const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 1024 ? 1 : 0);
   static const int dma = getenv("LV_PREFILL_DMA") ? atoi(getenv("LV_PREFILL_DMA")) : 0;
-  if (p.block_table) {
+  if (cfg == 2) {
+    if (p.block_table) launch_pp<true>(p, stream); else launch_pp<false>(p, stream);
+  } else if (p.block_table) {
     if (cfg == 1) { if (dma) launch_cfg<true, 8, 1, true>(p, stream); else launch_cfg<true, 8, 1, false>(p, stream); }
     else { if (dma) launch_cfg<true, 4, 1, true>(p, stream); else launch_cfg<true, 4, 1, false>(p, stream); }
   } else {

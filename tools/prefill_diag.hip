@@ -72,6 +72,11 @@ int main(int argc, char** argv) {
   const char* names[16] = {"barrier (wait for all waves)", "ds_write stage", "-", "issue next tile's loads",
                            "K_A reads, QK_A, K_B+V_A reads", "region 2: PV_A | exp(B)", "PV_B", "-",
                            "max(A) (+rescale)", "region 1: QK_B | exp(A)", "V_B reads issue, max(B)", "-", "-", "-", "-", "-"};
+  const char* names_pp[16] = {"L_K: rescale + exp half", "C_QK: 16 MFMA | exp", "L_V: mask, max, decision",
+                              "C_PV: 16 MFMA | exp", "barrier after L_K", "barrier after C_QK", "barrier after L_V",
+                              "barrier after C_PV", "L_V: K publish + loads", "L_V: V reads (+wait)", "L_K: V publish + loads", "L_K: K reads (+wait)", "-", "-", "-", "-"};
+  const char* cfg = getenv("LV_PREFILL_CFG");
+  if (cfg && atoi(cfg) == 2) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
   tot -= seg[15];
   for (int i = 0; i < 15; ++i)
     if (seg[i] > 0) printf("%-34s %6.2f %%   %8.0f ticks per (wave, tile)\n", names[i], 100.0 * seg[i] / tot, seg[i] / seg[15]);
