@@ -514,10 +514,10 @@ void prefill_attn_kernel(const PrefillParams p) {
 // w and w+4 share a SIMD) that run the same four-cluster program per K/V tile one cluster apart,
 // so each SIMD always has one wave in a matrix cluster beside its partner in a load cluster:
 //
-//   L_K(i)  read the K(i+1) fragments, second half of exp for tile i, apply a pending
+//   L_K(i)  read the K(i+1) and Q fragments, second half of exp for tile i, apply a pending
 //           accumulator rescale
 //   C_QK(i) S(i+1) = K(i+1) Q^T                                  (16 MFMAs, operands in registers)
-//   L_V(i)  publish K(i+2) and V(i+1) to LDS, issue the global loads of K(i+3) and V(i+2), read
+//   L_V(i)  publish V(i+1) and K(i+2) to LDS, issue the global loads of V(i+2) and K(i+3), read
 //           three quarters of the V(i) fragments, mask / row maximum / rescale decision of tile i+1
 //   C_PV(i) O += V(i)^T P(i)  beside the first half of exp for tile i+1          (16 MFMAs)
 //
@@ -535,7 +535,8 @@ void prefill_pp_kernel(const PrefillParams p) {
   constexpr int BM = 32 * NW;
   constexpr int NST = 2;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 32;   // tile rows between them
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];  // slot s: K at 2s, V at 2s+1
+  // slot s: K at 2s, V at 2s+1; then eight per-wave images of the wave's 32 Q rows
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes + NW * 8192];
   lds_byte* const lds3 = (lds_byte*)lds;
 
   const int G = p.num_heads / p.num_kv_heads;
@@ -564,14 +565,21 @@ void prefill_pp_kernel(const PrefillParams p) {
   const int my_row = wrow0 + c;
   const int my_lim = my_row + coff;
 
-  bf16x8 qf[8];
+  // Q^T fragments (B operand of S^T = K Q^T) are parked in a wave-private LDS image with the
+  // K swizzle and re-read into registers for each C_QK cluster: 32 registers that are then free
+  // during the other three clusters.
+  const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
+  const int kbase0 = (256 * c) | (16 * (h ^ xr));
+  const int qimg = 4 * kTileBytes + wave * 8192;
   {
     const int row_ld = min(my_row, Lq - 1);
     const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
+    bf16x8 qtmp[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    for (int s = 0; s < 8; ++s) qtmp[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(qf[s]));
+    for (int s = 0; s < 8; ++s)
+      *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(lds3 + qimg + (kbase0 ^ (32 * s))) = qtmp[s];
   }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
@@ -597,17 +605,23 @@ void prefill_pp_kernel(const PrefillParams p) {
       return static_cast<int64_t>(k_start) + kt0;
     }
   };
-  auto load_rows = [&](int tile, const uint16_t* base, uint32_t row_bytes, u32x4 (&reg)[NST]) {
-    if (tile >= ntiles) return;
-    const char* tb = reinterpret_cast<const char*>(base) + tile_row(tile) * row_bytes + col_bytes;
-    const int last = Lk - 1 - tile * BN;  // rows past the sequence end re-read its last row (masked later)
+  // per-thread byte offset inside a tile (same for every tile): the tile base stays in scalar
+  // registers and the loop carries no 64-bit vector address arithmetic
+  const uint32_t st_koff = static_cast<uint32_t>(st_r) * k_row_bytes + col_bytes;
+  const uint32_t st_voff = static_cast<uint32_t>(st_r) * v_row_bytes + col_bytes;
+  // Buffer loads: the tile base and extent live in a scalar descriptor, the per-thread offset is
+  // one 32-bit register, and rows past the sequence end read as zeros (they are masked later).
+  auto load_rows = [&](int tile, const uint16_t* base, uint32_t row_bytes, uint32_t st_off, u32x4 (&reg)[NST]) {
+    if (tile >= ntiles || (LV_ABL & 8)) return;
+    const char* tb = reinterpret_cast<const char*>(base) + tile_row(tile) * row_bytes;
+    const uint32_t rows = static_cast<uint32_t>(min(BN, Lk - tile * BN));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb), 0, rows * row_bytes, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const uint32_t r = static_cast<uint32_t>(min(st_r + RSTEP * i, last));
-      reg[i] = *reinterpret_cast<const u32x4*>(tb + r * row_bytes);
-    }
+    for (int i = 0; i < NST; ++i)
+      reg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, st_off, RSTEP * i * row_bytes, 0));
   };
   auto write_rows = [&](int byte_off, const u32x4 (&reg)[NST]) {
+    if (LV_ABL & 16) return;
 #pragma unroll
     for (int i = 0; i < NST; ++i)
       *reinterpret_cast<u32x4*>(lds + byte_off + 256 * RSTEP * i + st_lds) = reg[i];
@@ -629,19 +643,19 @@ void prefill_pp_kernel(const PrefillParams p) {
   //   K, d-step s:                 kbase ^ 32 s
   //   V^T, column block dt, rows +8 ("second"):   vbase ^ 64 dt ^ (second ? 2048 | 32 : 0)
   // so two registers stand in for sixteen; the XORs are redone where the reads are issued.
-  const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
   const int gi = lane >> 4;
   const int tq = (lane & 15) >> 2;
   const int tp = lane & 3;
-  const int kbase0 = (256 * c) | (16 * (h ^ xr));
   const int vbase0 = kTileBytes + lds_off(4 * (gi >> 1) + tq, 2 * (gi & 1) + (tp >> 1)) + 8 * (tp & 1);
 
   // K fragments of four d-steps (s0 .. s0+3) of a 32-key half
   auto load_kg = [&](bf16x8 (&kg)[4], int kbase, int byte_off, auto s0_c) {
     constexpr int S0 = decltype(s0_c)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (LV_ABL & 32) { asm volatile("" : "=v"(kg[j])); continue; }
       kg[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds3 + (kbase ^ (32 * (S0 + j))) + byte_off);
+    }
   };
   // V^T fragments of one 32-column block dt for the tile's four 16-key steps (index 2*half + s)
   auto load_vg = [&](bf16x8 (&vg)[4], int vbase, int byte_off, auto dt_c) {
@@ -650,6 +664,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int second = 0; second < 2; ++second) {
+        if (LV_ABL & 64) { if (second == 0) asm volatile("" : "=v"(vg[ks])); continue; }
         const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(lds3 + (vbase ^ (64 * DT) ^ (second * (2048 | 32))) + byte_off + 4096 * ks));
         vg[ks][4 * second + 0] = t[0];
@@ -658,16 +673,20 @@ void prefill_pp_kernel(const PrefillParams p) {
         vg[ks][4 * second + 3] = t[3];
       }
   };
-  auto qk4 = [&](const bf16x8 (&kg)[4], f32x16& sacc, auto s0_c) {
-    constexpr int S0 = decltype(s0_c)::value;
+  auto qk4 = [&](const bf16x8 (&kg)[4], const bf16x8 (&qg)[4], f32x16& sacc) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg[j], qf[S0 + j], sacc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      if (LV_ABL & 4) { LV_KEEP(kg[j]); LV_KEEP(qg[j]); continue; }
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg[j], qg[j], sacc, 0, 0, 0);
+    }
   };
   auto pv4 = [&](const bf16x8 (&vg)[4], const bf16x8 (&pf)[2][2], auto dt_c) {
     constexpr int DT = decltype(dt_c)::value;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
+      if (LV_ABL & 2) { LV_KEEP(vg[ks]); LV_KEEP(pf[ks >> 1][ks & 1]); continue; }
       oacc[DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vg[ks], pf[ks >> 1][ks & 1], oacc[DT], 0, 0, 0);
+    }
   };
   // scheduling hint: N x {1 MFMA, 3 vector ALU, 1 transcendental}
   auto mix = [&](auto n_c) {
@@ -691,12 +710,16 @@ void prefill_pp_kernel(const PrefillParams p) {
       }
     }
     float mx = fmaxf(sa[0], sb[0]);
+    if (!(LV_ABL & 4096)) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
-    const unsigned mb = __builtin_bit_cast(unsigned, mx);
-    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-    mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    if (__builtin_amdgcn_ballot_w64(mx - m_run > defer_raw) != 0) {
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
+    }
+    if (!(LV_ABL & 1024)) {
+      const unsigned mb = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
+    if ((LV_ABL & 2048) ? (tile == 0) : (__builtin_amdgcn_ballot_w64(mx - m_run > defer_raw) != 0)) {
       const float m_new = fmaxf(m_run, mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * cexp);
@@ -726,6 +749,7 @@ void prefill_pp_kernel(const PrefillParams p) {
   // a quarter of a 32-key half's exp: P = exp2(S*c - m*c) for registers 4q .. 4q+3
   auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float mc, float& psum, auto q_c) {
     constexpr int Q = decltype(q_c)::value;
+    if (LV_ABL & 512) { if (Q == 0) { asm volatile("" : "=v"(pf[0])); asm volatile("" : "=v"(pf[1])); } return; }
 #pragma unroll
     for (int r = 4 * Q; r < 4 * Q + 4; ++r) {
       const float pe = (LV_ABL & 1) ? fmaf(sacc[r], cexp, -mc) : __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
@@ -752,6 +776,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     asm volatile("" : "+v"(kbase), "+v"(vbase));
     LV_STAMP_COUNT
     bf16x8 kx[4][4];   // K fragments: [32-key half * 2 + d-step group][4]
+    bf16x8 qx[2][4];   // Q^T fragments: [d-step group][4]
     bf16x8 vx[3][4];   // V^T fragments: [column block][16-key step]; block 3 reuses block 0's registers
     // ---- L_K(i)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
@@ -761,6 +786,8 @@ void prefill_pp_kernel(const PrefillParams p) {
       load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
       load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
       load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
+      load_kg(qx[0], kbase, qimg, IntC<0>{});
+      load_kg(qx[1], kbase, qimg, IntC<4>{});
     }
     LV_STAMP(11)
     if constexpr (CUR) {
@@ -782,7 +809,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(0)
-    __syncthreads();
+    if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(4)
     __builtin_amdgcn_sched_barrier(0);
     // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
@@ -790,20 +817,19 @@ void prefill_pp_kernel(const PrefillParams p) {
     if constexpr (NEXT) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { S[NPAR][0][r] = 0.f; S[NPAR][1][r] = 0.f; }
-      qk4(kx[0], S[NPAR][0], IntC<0>{});
-      qk4(kx[1], S[NPAR][0], IntC<4>{});
-      qk4(kx[2], S[NPAR][1], IntC<0>{});
-      qk4(kx[3], S[NPAR][1], IntC<4>{});
+      qk4(kx[0], qx[0], S[NPAR][0]);
+      qk4(kx[1], qx[1], S[NPAR][0]);
+      qk4(kx[2], qx[0], S[NPAR][1]);
+      qk4(kx[3], qx[1], S[NPAR][1]);
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(1)
-    __syncthreads();
+    if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(5)
     __builtin_amdgcn_sched_barrier(0);
     // ---- L_V(i)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
-    // All staging sits here, so every global load has a whole tile interval to land and the
-    // wait in front of the LDS writes is exact. Slots: K(i+2) replaces K(i), last read in
+    // All staging sits here, so every global load has a whole tile interval to land. Slots: K(i+2) replaces K(i), last read in
     // C_QK(i-1); V(i+1) replaces V(i-1), last read in C_PV(i-1), one cluster before the second
     // group gets here.
     if constexpr (NEXT) {
@@ -811,8 +837,8 @@ void prefill_pp_kernel(const PrefillParams p) {
         write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);   // V(i+1)
         if (i + 2 < ntiles) write_rows(PAR * 2 * kTileBytes, kreg);   // K(i+2)
         __builtin_amdgcn_sched_barrier(0);
-        load_rows(i + 2, p.v, v_row_bytes, vreg);
-        load_rows(i + 3, p.k, k_row_bytes, kreg);
+        load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
+        load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
       }
     }
     LV_STAMP(8)
@@ -825,7 +851,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     if constexpr (NEXT) head(i + 1, S[NPAR][0], S[NPAR][1]);
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(2)
-    __syncthreads();
+    if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(6)
     __builtin_amdgcn_sched_barrier(0);
     // ---- C_PV(i): O += V(i)^T P(i) beside the first half of exp for tile i+1
@@ -855,17 +881,17 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(3)
-    __syncthreads();
+    if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(7)
     __builtin_amdgcn_sched_barrier(0);
   };
 
   if (ntiles > 0) {
     // prologue: K(0) published, K(1) and V(0) in flight
-    load_rows(0, p.k, k_row_bytes, kreg);
+    load_rows(0, p.k, k_row_bytes, st_koff, kreg);
     write_rows(0, kreg);
-    load_rows(1, p.k, k_row_bytes, kreg);
-    load_rows(0, p.v, v_row_bytes, vreg);
+    load_rows(1, p.k, k_row_bytes, st_koff, kreg);
+    load_rows(0, p.v, v_row_bytes, st_voff, vreg);
     __syncthreads();
     if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
     body(-1, IntC<1>{}, IntC<0>{}, IntC<1>{});
