@@ -514,16 +514,16 @@ void prefill_attn_kernel(const PrefillParams p) {
 // w and w+4 share a SIMD) that run the same four-cluster program per K/V tile one cluster apart,
 // so each SIMD always has one wave in a matrix cluster beside its partner in a load cluster:
 //
-//   L_K(i)  read the K(i+1) and Q fragments, second half of exp for tile i, apply a pending
-//           accumulator rescale
+//   L_K(i)  read the K(i+1) and Q fragments (and apply a pending accumulator rescale, rare)
 //   C_QK(i) S(i+1) = K(i+1) Q^T                                  (16 MFMAs, operands in registers)
 //   L_V(i)  publish V(i+1) and K(i+2) to LDS, issue the global loads of V(i+2) and K(i+3), read
-//           three quarters of the V(i) fragments, mask / row maximum / rescale decision of tile i+1
-//   C_PV(i) O += V(i)^T P(i)  beside the first half of exp for tile i+1          (16 MFMAs)
+//           three quarters of the V(i) fragments (causal mask of tile i+1 on diagonal tiles)
+//   C_PV(i) O += V(i)^T P(i) with the whole softmax of tile i+1 (row maximum, running-max update,
+//           exponentials) issued between its MFMAs                                  (16 MFMAs)
 //
-// One workgroup barrier closes every cluster. The softmax of a tile is spread over three
-// clusters, so the P of tile i and the scores of tile i+1 are live together (two named register
-// sets, alternating with the tile parity). A rescale decided for tile i+1 while P(i) is still
+// One workgroup barrier closes every cluster. Load clusters carry no vector ALU work: beside the
+// partner's matrix cluster it would wait for issue slots. The P of tile i and the scores of tile
+// i+1 are live together (two named register sets, alternating with the tile parity). A rescale decided for tile i+1 while P(i) is still
 // to be added is applied to l at once and to O in the next L_K, after O += V(i)^T P(i).
 #ifndef LV_PP_LPRIO
 #define LV_PP_LPRIO 2
@@ -577,9 +577,14 @@ void prefill_pp_kernel(const PrefillParams p) {
     bf16x8 qtmp[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qtmp[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    // Q is stored pre-multiplied by scale*log2(e), so scores come out of the MFMA in log2 units
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(lds3 + qimg + (kbase0 ^ (32 * s))) = qtmp[s];
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * p.scale_log2e);
+      *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(lds3 + qimg + (kbase0 ^ (32 * s))) = t;
+    }
   }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
@@ -635,8 +640,6 @@ void prefill_pp_kernel(const PrefillParams p) {
   float m_run = -INFINITY, l_run = 0.f;
   float pend_alpha = 1.f;
   bool pend = false;
-  const float cexp = p.scale_log2e;
-  const float defer_raw = kDeferLog2 / cexp;
 
   // LDS read addresses inside slot 0. The swizzled fragment addresses of prefill_attn_kernel
   // differ from one per-lane base only by XOR with compile-time constants:
@@ -689,18 +692,16 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
   };
   // scheduling hint: N x {1 MFMA, 3 vector ALU, 1 transcendental}
-  auto mix = [&](auto n_c) {
-#pragma unroll
-    for (int g = 0; g < decltype(n_c)::value; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-    }
+  // max(a, b, c) in one instruction: fmaxf on MFMA outputs compiles to a canonicalising
+  // v_max per operand plus the max itself
+  auto max3 = [](float a, float b, float c) -> float {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
   };
-  // mask, row maximum and rescale decision of the tile whose scores are (sa, sb)
-  auto head = [&](int tile, f32x16& sa, f32x16& sb) {
+  // causal mask of a tile that reaches the diagonal (uniform branch; runs in a load cluster)
+  auto mask_tile = [&](int tile, f32x16& sa, f32x16& sb) {
     const int kt0 = tile * BN;
-    if (LV_ABL & 128) { if (tile == 0) m_run = 0.f; return; }
     if (kt0 + 63 > wrow0 + coff) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -709,103 +710,97 @@ void prefill_pp_kernel(const PrefillParams p) {
         if (key + 32 > my_lim) sb[r] = -INFINITY;
       }
     }
-    float mx = fmaxf(sa[0], sb[0]);
-    if (!(LV_ABL & 4096)) {
+  };
+  // The MFMA accumulator of S(i+1) is seeded with -m_off, the running maximum after tile i (0
+  // while a row has seen no key), so scores arrive as s - m_off in log2 units and P = exp2 of
+  // them with no further arithmetic, as long as the maximum does not move. head() takes the row
+  // maximum of such a tile; when some row of the wave outgrows m_off by more than the deferral
+  // threshold (or has no maximum yet) it moves the maxima, shifts the tile's scores by the
+  // difference, rescales l at once and leaves the O rescale pending for the next L_K, after the
+  // P that is still at the old scale has been added.
+  auto head = [&](f32x16& sa, f32x16& sb) {
+    if (LV_ABL & 128) { m_run = 0.f; return; }
+    float a[10];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa[r], sb[r]));
+    for (int j = 0; j < 5; ++j) {
+      a[j] = max3(sa[3 * j], sa[3 * j + 1], sa[3 * j + 2]);
+      a[5 + j] = max3(sb[3 * j], sb[3 * j + 1], sb[3 * j + 2]);
     }
-    if (!(LV_ABL & 1024)) {
-      const unsigned mb = __builtin_bit_cast(unsigned, mx);
-      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
-    if ((LV_ABL & 2048) ? (tile == 0) : (__builtin_amdgcn_ballot_w64(mx - m_run > defer_raw) != 0)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * cexp);
+    const float b0 = max3(a[0], a[1], a[2]);
+    const float b1 = max3(a[3], a[4], a[5]);
+    const float b2 = max3(a[6], a[7], a[8]);
+    const float b3 = max3(a[9], sa[15], sb[15]);
+    float mx = fmaxf(max3(b0, b1, b2), b3);
+    const unsigned mb = __builtin_bit_cast(unsigned, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    const bool fresh = m_run == -INFINITY;
+    if (__builtin_amdgcn_ballot_w64(fresh || mx > kDeferLog2) != 0) {
+      const float m_off = fresh ? 0.f : m_run;
+      const float m_new = fmaxf(m_run, m_off + mx);
+      const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_off;
+      const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] -= delta; sb[r] -= delta; }
+      l_run *= alpha;
       m_run = m_new;
-      l_run *= alpha;       // every P summed so far is at the old scale
-      pend_alpha = alpha;   // O follows once the P still at the old scale has been added
+      pend_alpha = alpha;
       pend = true;
     }
   };
-  auto tail = [&](const f32x16& sacc, bf16x8 (&pf)[2]) -> float {
-    const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
-    float psum = 0.f;
+  // a quarter of a 32-key half's exp: P = exp2(S) for registers 4q .. 4q+3
+  auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float& psum, auto q_c) {
+    constexpr int Q = decltype(q_c)::value;
+    if (LV_ABL & 512) { if (Q == 0) { asm volatile("" : "=v"(pf[0])); asm volatile("" : "=v"(pf[1])); } return; }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
+    for (int r = 4 * Q; r < 4 * Q + 4; ++r) {
+      const float pe = (LV_ABL & 1) ? sacc[r] : __builtin_amdgcn_exp2f(sacc[r]);
       psum += pe;
       pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
     }
-    return psum;
+  };
+  // scheduling hint for a slice of 4 MFMAs beside NV plain and NT transcendental vector
+  // instructions per MFMA
+  auto mix4 = [&](auto nv_c, auto nt_c) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, decltype(nv_c)::value, 0);
+      if (decltype(nt_c)::value > 0) __builtin_amdgcn_sched_group_barrier(0x400, decltype(nt_c)::value, 0);
+    }
   };
 
   LV_STAMP_DECL
   f32x16 S[2][2];      // [tile parity][32-key half] scores
   bf16x8 P[2][2][2];   // [tile parity][32-key half][k-step] probabilities
 
-  // One tile interval. PAR = parity of tile i; CUR: tile i exists (i >= 0); NEXT: tile i+1 exists.
-  // a quarter of a 32-key half's exp: P = exp2(S*c - m*c) for registers 4q .. 4q+3
-  auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float mc, float& psum, auto q_c) {
-    constexpr int Q = decltype(q_c)::value;
-    if (LV_ABL & 512) { if (Q == 0) { asm volatile("" : "=v"(pf[0])); asm volatile("" : "=v"(pf[1])); } return; }
-#pragma unroll
-    for (int r = 4 * Q; r < 4 * Q + 4; ++r) {
-      const float pe = (LV_ABL & 1) ? fmaf(sacc[r], cexp, -mc) : __builtin_amdgcn_exp2f(fmaf(sacc[r], cexp, -mc));
-      psum += pe;
-      pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
-    }
-  };
-  // scheduling hint for a slice of 4 MFMAs beside a quarter of exp work
-  auto mix4 = [&]() {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-    }
-  };
-
-  auto body = [&](int i, auto par_c, auto cur_c, auto next_c) {
+  // One tile interval. PAR = parity of tile i; CUR: tile i exists (false only for i = -1).
+  auto body = [&](int i, auto par_c, auto cur_c) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr int NPAR = PAR ^ 1;
     constexpr bool CUR = decltype(cur_c)::value != 0;
-    constexpr bool NEXT = decltype(next_c)::value != 0;
     int kbase = kbase0, vbase = vbase0;   // opaque copies: keeps the XORs next to the reads
     asm volatile("" : "+v"(kbase), "+v"(vbase));
     LV_STAMP_COUNT
     bf16x8 kx[4][4];   // K fragments: [32-key half * 2 + d-step group][4]
     bf16x8 qx[2][4];   // Q^T fragments: [d-step group][4]
     bf16x8 vx[3][4];   // V^T fragments: [column block][16-key step]; block 3 reuses block 0's registers
-    // ---- L_K(i)
+    // ---- L_K(i): loads only (vector ALU work here would compete with the partner's C cluster)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
-    LV_STAMP(10)
-    if constexpr (NEXT) {
-      load_kg(kx[0], kbase, NPAR * 2 * kTileBytes, IntC<0>{});
-      load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
-      load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
-      load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
-      load_kg(qx[0], kbase, qimg, IntC<0>{});
-      load_kg(qx[1], kbase, qimg, IntC<4>{});
-    }
-    LV_STAMP(11)
+    load_kg(kx[0], kbase, NPAR * 2 * kTileBytes, IntC<0>{});
+    load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
+    load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
+    load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
+    load_kg(qx[0], kbase, qimg, IntC<0>{});
+    load_kg(qx[1], kbase, qimg, IntC<4>{});
     if constexpr (CUR) {
-      if (pend) {
+      if (pend) {   // rare: O += V(i-1)^T P(i-1) is complete, P(i) is already at the new scale
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[dt][r] *= pend_alpha;
         pend = false;
       }
-      // second half of exp for tile i, while the K reads are in flight
-      const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
-      float ps = 0.f;
-      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<0>{});
-      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<1>{});
-      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<2>{});
-      tail_q(S[PAR][1], P[PAR][1], mc, ps, IntC<3>{});
-      l_run += ps;
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(0)
@@ -814,14 +809,15 @@ void prefill_pp_kernel(const PrefillParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (NEXT) {
+    {
+      const float seed = (m_run == -INFINITY) ? 0.f : -m_run;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { S[NPAR][0][r] = 0.f; S[NPAR][1][r] = 0.f; }
-      qk4(kx[0], qx[0], S[NPAR][0]);
-      qk4(kx[1], qx[1], S[NPAR][0]);
-      qk4(kx[2], qx[0], S[NPAR][1]);
-      qk4(kx[3], qx[1], S[NPAR][1]);
+      for (int r = 0; r < 16; ++r) { S[NPAR][0][r] = seed; S[NPAR][1][r] = seed; }
     }
+    qk4(kx[0], qx[0], S[NPAR][0]);
+    qk4(kx[1], qx[1], S[NPAR][0]);
+    qk4(kx[2], qx[0], S[NPAR][1]);
+    qk4(kx[3], qx[1], S[NPAR][1]);
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(1)
     if (!(LV_ABL & 256)) __syncthreads();
@@ -829,17 +825,15 @@ void prefill_pp_kernel(const PrefillParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- L_V(i)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
-    // All staging sits here, so every global load has a whole tile interval to land. Slots: K(i+2) replaces K(i), last read in
-    // C_QK(i-1); V(i+1) replaces V(i-1), last read in C_PV(i-1), one cluster before the second
-    // group gets here.
-    if constexpr (NEXT) {
-      if (i + 1 < ntiles) {
-        write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);   // V(i+1)
-        if (i + 2 < ntiles) write_rows(PAR * 2 * kTileBytes, kreg);   // K(i+2)
-        __builtin_amdgcn_sched_barrier(0);
-        load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
-        load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
-      }
+    // All staging sits here, so every global load has a whole tile interval to land. Slots:
+    // K(i+2) replaces K(i), last read in L_K(i-1); V(i+1) replaces V(i-1), last read in
+    // C_PV(i-1), one cluster before the second group gets here.
+    if (i + 1 < ntiles) {
+      write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);   // V(i+1)
+      if (i + 2 < ntiles) write_rows(PAR * 2 * kTileBytes, kreg);   // K(i+2)
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
+      load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
     }
     LV_STAMP(8)
     if constexpr (CUR) {
@@ -848,36 +842,42 @@ void prefill_pp_kernel(const PrefillParams p) {
       load_vg(vx[2], vbase, PAR * 2 * kTileBytes, IntC<2>{});
     }
     LV_STAMP(9)
-    if constexpr (NEXT) head(i + 1, S[NPAR][0], S[NPAR][1]);
+    mask_tile(i + 1, S[NPAR][0], S[NPAR][1]);
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(2)
     if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(6)
     __builtin_amdgcn_sched_barrier(0);
-    // ---- C_PV(i): O += V(i)^T P(i) beside the first half of exp for tile i+1
+    // ---- C_PV(i): O += V(i)^T P(i); in the MFMAs' shadow the whole softmax of tile i+1:
+    // slice 0 the row maximum and running-max update, slices 1-3 the exponentials
     __builtin_amdgcn_s_setprio(0);
     {
-      const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * cexp;
       float ps = 0.f;
       if constexpr (CUR) pv4(vx[0], P[PAR], IntC<0>{});
-      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<0>{});
-      if constexpr (CUR && NEXT) mix4();
+      head(S[NPAR][0], S[NPAR][1]);
+      if constexpr (CUR) mix4(IntC<6>{}, IntC<0>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<3>{});
       if constexpr (CUR) pv4(vx[1], P[PAR], IntC<1>{});
-      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<1>{});
-      if constexpr (CUR && NEXT) mix4();
+      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<0>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<1>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<2>{});
+      asm volatile("" ::"v"(ps));
+      if constexpr (CUR) mix4(IntC<5>{}, IntC<3>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) pv4(vx[2], P[PAR], IntC<2>{});
-      if constexpr (NEXT) tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<2>{});
-      if constexpr (CUR && NEXT) mix4();
+      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<3>{});
+      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<0>{});
+      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<1>{});
+      asm volatile("" ::"v"(ps), "v"(P[NPAR][0][0]), "v"(P[NPAR][0][1]));
+      if constexpr (CUR) mix4(IntC<5>{}, IntC<3>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) pv4(vx[0], P[PAR], IntC<3>{});
-      if constexpr (NEXT) {
-        tail_q(S[NPAR][0], P[NPAR][0], mc, ps, IntC<3>{});
-        l_run += ps;
-      }
-      if constexpr (CUR && NEXT) mix4();
+      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<2>{});
+      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<3>{});
+      l_run += ps;
+      asm volatile("" ::"v"(l_run), "v"(P[NPAR][1][0]), "v"(P[NPAR][1][1]));
+      if constexpr (CUR) mix4(IntC<3>{}, IntC<2>{});
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(3)
@@ -894,14 +894,14 @@ void prefill_pp_kernel(const PrefillParams p) {
     load_rows(0, p.v, v_row_bytes, st_voff, vreg);
     __syncthreads();
     if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
-    body(-1, IntC<1>{}, IntC<0>{}, IntC<1>{});
+    body(-1, IntC<1>{}, IntC<0>{});
     // Every interval also forms the scores of tile i+1; past the last tile they are computed from
     // stale LDS and fully masked (every key of tile ntiles lies beyond every row's causal limit),
     // which leaves the running statistics untouched and keeps the loop body free of branches
     // around its matrix clusters.
     for (int i = 0; i < ntiles; i += 2) {
-      body(i, IntC<0>{}, IntC<1>{}, IntC<1>{});
-      if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{}, IntC<1>{});
+      body(i, IntC<0>{}, IntC<1>{});
+      if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{});
     }
     if (grp == 0) __syncthreads();
   }
