@@ -535,8 +535,8 @@ void prefill_pp_kernel(const PrefillParams p) {
   constexpr int BM = 32 * NW;
   constexpr int NST = 2;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 32;   // tile rows between them
-  // slot s: K at 2s, V at 2s+1; then eight per-wave images of the wave's 32 Q rows
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes + NW * 8192];
+  // slot s: K at 2s, V at 2s+1
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
 
   const int G = p.num_heads / p.num_kv_heads;
@@ -565,25 +565,22 @@ void prefill_pp_kernel(const PrefillParams p) {
   const int my_row = wrow0 + c;
   const int my_lim = my_row + coff;
 
-  // Q^T fragments (B operand of S^T = K Q^T) are parked in a wave-private LDS image with the
-  // K swizzle and re-read into registers for each C_QK cluster: 32 registers that are then free
-  // during the other three clusters.
+  // Q^T fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e) so scores come out
+  // of the MFMA in log2 units
   const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
   const int kbase0 = (256 * c) | (16 * (h ^ xr));
-  const int qimg = 4 * kTileBytes + wave * 8192;
+  bf16x8 qf[8];
   {
     const int row_ld = min(my_row, Lq - 1);
     const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
     bf16x8 qtmp[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qtmp[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-    // Q is stored pre-multiplied by scale*log2(e), so scores come out of the MFMA in log2 units
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      bf16x8 t;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * p.scale_log2e);
-      *reinterpret_cast<__attribute__((address_space(3))) bf16x8*>(lds3 + qimg + (kbase0 ^ (32 * s))) = t;
+      for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * p.scale_log2e);
+      asm volatile("" ::"v"(qf[s]));   // retire the loads before the tile loop
     }
   }
 
@@ -676,11 +673,12 @@ void prefill_pp_kernel(const PrefillParams p) {
         vg[ks][4 * second + 3] = t[3];
       }
   };
-  auto qk4 = [&](const bf16x8 (&kg)[4], const bf16x8 (&qg)[4], f32x16& sacc) {
+  auto qk4 = [&](const bf16x8 (&kg)[4], auto s0_c, const f32x16& cin, f32x16& sacc) {
+    constexpr int S0 = decltype(s0_c)::value;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (LV_ABL & 4) { LV_KEEP(kg[j]); LV_KEEP(qg[j]); continue; }
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg[j], qg[j], sacc, 0, 0, 0);
+      if (LV_ABL & 4) { LV_KEEP(kg[j]); continue; }
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kg[j], qf[S0 + j], j == 0 ? cin : sacc, 0, 0, 0);
     }
   };
   auto pv4 = [&](const bf16x8 (&vg)[4], const bf16x8 (&pf)[2][2], auto dt_c) {
@@ -719,7 +717,7 @@ void prefill_pp_kernel(const PrefillParams p) {
   // difference, rescales l at once and leaves the O rescale pending for the next L_K, after the
   // P that is still at the old scale has been added.
   auto head = [&](f32x16& sa, f32x16& sb) {
-    if (LV_ABL & 128) { m_run = 0.f; return; }
+    if (LV_ABL & 128) { LV_KEEP(sa); LV_KEEP(sb); m_run = 0.f; return; }
     float a[10];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -731,9 +729,11 @@ void prefill_pp_kernel(const PrefillParams p) {
     const float b2 = max3(a[6], a[7], a[8]);
     const float b3 = max3(a[9], sa[15], sb[15]);
     float mx = fmaxf(max3(b0, b1, b2), b3);
+    if (LV_ABL & 1024) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
     const unsigned mb = __builtin_bit_cast(unsigned, mx);
     const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
     mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    if (LV_ABL & 2048) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
     const bool fresh = m_run == -INFINITY;
     if (__builtin_amdgcn_ballot_w64(fresh || mx > kDeferLog2) != 0) {
       const float m_off = fresh ? 0.f : m_run;
@@ -749,7 +749,8 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
   };
   // a quarter of a 32-key half's exp: P = exp2(S) for registers 4q .. 4q+3
-  auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float& psum, auto q_c) {
+  auto tail_q = [&](const f32x16& sacc, bf16x8 (&pf)[2], float (&ps4)[4], auto q_c) {
+    float& psum = ps4[decltype(q_c)::value];
     constexpr int Q = decltype(q_c)::value;
     if (LV_ABL & 512) { if (Q == 0) { asm volatile("" : "=v"(pf[0])); asm volatile("" : "=v"(pf[1])); } return; }
 #pragma unroll
@@ -783,7 +784,6 @@ void prefill_pp_kernel(const PrefillParams p) {
     asm volatile("" : "+v"(kbase), "+v"(vbase));
     LV_STAMP_COUNT
     bf16x8 kx[4][4];   // K fragments: [32-key half * 2 + d-step group][4]
-    bf16x8 qx[2][4];   // Q^T fragments: [d-step group][4]
     bf16x8 vx[3][4];   // V^T fragments: [column block][16-key step]; block 3 reuses block 0's registers
     // ---- L_K(i): loads only (vector ALU work here would compete with the partner's C cluster)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
@@ -791,8 +791,12 @@ void prefill_pp_kernel(const PrefillParams p) {
     load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
     load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
     load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
-    load_kg(qx[0], kbase, qimg, IntC<0>{});
-    load_kg(qx[1], kbase, qimg, IntC<4>{});
+    // K(i+2) replaces K(i), last read in L_K(i-1); its rows were requested in L_K(i-1)
+    if (i + 2 < ntiles) {
+      write_rows(PAR * 2 * kTileBytes, kreg);
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
+    }
     if constexpr (CUR) {
       if (pend) {   // rare: O += V(i-1)^T P(i-1) is complete, P(i) is already at the new scale
 #pragma unroll
@@ -810,14 +814,27 @@ void prefill_pp_kernel(const PrefillParams p) {
     // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
     __builtin_amdgcn_s_setprio(0);
     {
+      // one splat of -m feeds the first MFMA of both 32-key halves as its C operand
       const float seed = (m_run == -INFINITY) ? 0.f : -m_run;
+      f32x16 seedv;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { S[NPAR][0][r] = seed; S[NPAR][1][r] = seed; }
+      for (int r = 0; r < 16; ++r) seedv[r] = seed;
+      float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+      qk4(kx[0], IntC<0>{}, seedv, S[NPAR][0]);
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<2>{});
+      if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      qk4(kx[1], IntC<4>{}, S[NPAR][0], S[NPAR][0]);
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<3>{});
+      if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      qk4(kx[2], IntC<0>{}, seedv, S[NPAR][1]);
+      qk4(kx[3], IntC<4>{}, S[NPAR][1], S[NPAR][1]);
+      if constexpr (CUR) {
+        l_run += ps4[2] + ps4[3];
+        asm volatile("" ::"v"(l_run), "v"(P[PAR][1][0]), "v"(P[PAR][1][1]));
+      }
     }
-    qk4(kx[0], qx[0], S[NPAR][0]);
-    qk4(kx[1], qx[1], S[NPAR][0]);
-    qk4(kx[2], qx[0], S[NPAR][1]);
-    qk4(kx[3], qx[1], S[NPAR][1]);
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(1)
     if (!(LV_ABL & 256)) __syncthreads();
@@ -825,15 +842,12 @@ void prefill_pp_kernel(const PrefillParams p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- L_V(i)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
-    // All staging sits here, so every global load has a whole tile interval to land. Slots:
-    // K(i+2) replaces K(i), last read in L_K(i-1); V(i+1) replaces V(i-1), last read in
-    // C_PV(i-1), one cluster before the second group gets here.
+    // V(i+1) replaces V(i-1), last read in C_PV(i-1), one cluster before the second group gets
+    // here; its rows were requested in L_V(i-1)
     if (i + 1 < ntiles) {
-      write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);   // V(i+1)
-      if (i + 2 < ntiles) write_rows(PAR * 2 * kTileBytes, kreg);   // K(i+2)
+      write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);
       __builtin_amdgcn_sched_barrier(0);
       load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
-      load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
     }
     LV_STAMP(8)
     if constexpr (CUR) {
@@ -852,32 +866,30 @@ void prefill_pp_kernel(const PrefillParams p) {
     // slice 0 the row maximum and running-max update, slices 1-3 the exponentials
     __builtin_amdgcn_s_setprio(0);
     {
-      float ps = 0.f;
+      float ps4[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (CUR) pv4(vx[0], P[PAR], IntC<0>{});
       head(S[NPAR][0], S[NPAR][1]);
       if constexpr (CUR) mix4(IntC<6>{}, IntC<0>{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (CUR) load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<3>{});
+      if constexpr (CUR) { if (!(LV_ABL & 8192)) load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<3>{}); }
       if constexpr (CUR) pv4(vx[1], P[PAR], IntC<1>{});
-      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<0>{});
-      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<1>{});
-      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<2>{});
-      asm volatile("" ::"v"(ps));
-      if constexpr (CUR) mix4(IntC<5>{}, IntC<3>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<0>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<1>{});
+      asm volatile("" ::"v"(ps4[0]), "v"(ps4[1]));
+      if constexpr (CUR) mix4(IntC<3>{}, IntC<2>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) pv4(vx[2], P[PAR], IntC<2>{});
-      tail_q(S[NPAR][0], P[NPAR][0], ps, IntC<3>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<0>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<1>{});
-      asm volatile("" ::"v"(ps), "v"(P[NPAR][0][0]), "v"(P[NPAR][0][1]));
-      if constexpr (CUR) mix4(IntC<5>{}, IntC<3>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<2>{});
+      tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<3>{});
+      asm volatile("" ::"v"(ps4[2]), "v"(ps4[3]), "v"(P[NPAR][0][0]), "v"(P[NPAR][0][1]));
+      if constexpr (CUR) mix4(IntC<3>{}, IntC<2>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) pv4(vx[0], P[PAR], IntC<3>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<2>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps, IntC<3>{});
-      l_run += ps;
-      asm volatile("" ::"v"(l_run), "v"(P[NPAR][1][0]), "v"(P[NPAR][1][1]));
-      if constexpr (CUR) mix4(IntC<3>{}, IntC<2>{});
+      tail_q(S[NPAR][1], P[NPAR][1], ps4, IntC<0>{});
+      tail_q(S[NPAR][1], P[NPAR][1], ps4, IntC<1>{});
+      l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+      asm volatile("" ::"v"(l_run), "v"(P[NPAR][1][0]));
+      if constexpr (CUR) mix4(IntC<4>{}, IntC<2>{});
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(3)
@@ -887,11 +899,11 @@ void prefill_pp_kernel(const PrefillParams p) {
   };
 
   if (ntiles > 0) {
-    // prologue: K(0) published, K(1) and V(0) in flight
+    // prologue: K(0) published, K(1) and V(0) in flight (L_K(-1) publishes K(1), L_V(-1) V(0))
     load_rows(0, p.k, k_row_bytes, st_koff, kreg);
+    load_rows(0, p.v, v_row_bytes, st_voff, vreg);
     write_rows(0, kreg);
     load_rows(1, p.k, k_row_bytes, st_koff, kreg);
-    load_rows(0, p.v, v_row_bytes, st_voff, vreg);
     __syncthreads();
     if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
     body(-1, IntC<1>{}, IntC<0>{});
