@@ -17,6 +17,8 @@
 //     with lane^32, and the bf16-rounded P registers are directly the B operand of
 //     O^T += V^T P^T (same lane = same query row), with no LDS round trip for P.
 //   * fp32 scores, statistics and accumulation; exp2 with scale*log2(e) folded into one FMA.
+// Two kernels share these ideas: prefill_attn_kernel (4 or 8 free-running waves, one barrier per
+// tile) and prefill_pp_kernel (8 waves in two groups that alternate matrix and load clusters).
 #include <stdlib.h>
 
 #include "lv_kernels.h"
@@ -56,6 +58,8 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); __builtin_amdgcn_sched_barrier(0); \
   st_acc[i] += st_now - st_prev; st_prev = st_now; }
 #define LV_STAMP_COUNT st_acc[15] += 1;
+#define LV_CLOCK_BEGIN unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#define LV_CLOCK_END st_acc[12] = __builtin_amdgcn_s_memtime() - ck_t0; st_acc[13] = __builtin_amdgcn_s_memrealtime() - ck_r0;
 #define LV_STAMP_FLUSH if (g_lv_stamp_buf && lane == 0) { \
   unsigned long long* d = g_lv_stamp_buf + static_cast<size_t>(blockIdx.x) * 128 + wave * 16; \
   for (int i = 0; i < 16; ++i) d[i] = st_acc[i]; }
@@ -64,6 +68,8 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
 #define LV_STAMP(i)
 #define LV_STAMP_COUNT
 #define LV_STAMP_FLUSH
+#define LV_CLOCK_BEGIN
+#define LV_CLOCK_END
 #endif
 
 template <int V>
@@ -906,6 +912,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     load_rows(1, p.k, k_row_bytes, st_koff, kreg);
     __syncthreads();
     if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
+    LV_CLOCK_BEGIN
     body(-1, IntC<1>{}, IntC<0>{});
     // Every interval also forms the scores of tile i+1; past the last tile they are computed from
     // stale LDS and fully masked (every key of tile ntiles lies beyond every row's causal limit),
@@ -916,6 +923,7 @@ void prefill_pp_kernel(const PrefillParams p) {
       if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{});
     }
     if (grp == 0) __syncthreads();
+    LV_CLOCK_END
   }
   LV_STAMP_FLUSH
 
@@ -956,10 +964,14 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   if (static_cast<int64_t>((p.max_seqlen_q + 127) / 128) * p.num_heads * p.batch > INT32_MAX)
     return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
-  //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row.
-  static const int force = getenv("LV_PREFILL_CFG") ? atoi(getenv("LV_PREFILL_CFG")) : -1;
-  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 1024 ? 1 : 0);
-  static const int dma = getenv("LV_PREFILL_DMA") ? atoi(getenv("LV_PREFILL_DMA")) : 0;
+  //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
+  // cfg 2: the phase-locked 8-wave kernel (long prompts).
+  // LV_PREFILL_CFG / LV_PREFILL_DMA override the choice (read on every call: tests switch them).
+  const char* env_cfg = getenv("LV_PREFILL_CFG");
+  const char* env_dma = getenv("LV_PREFILL_DMA");
+  const int force = env_cfg ? atoi(env_cfg) : -1;
+  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q >= 1024 ? 1 : 0));
+  const int dma = env_dma ? atoi(env_dma) : 0;
   if (cfg == 2) {
     if (p.block_table) launch_pp<true>(p, stream); else launch_pp<false>(p, stream);
   } else if (p.block_table) {

@@ -9,6 +9,17 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-2
 
 
+@pytest.fixture(autouse=True, params=["auto", "0", "1", "2"], ids=lambda c: f"cfg-{c}")
+def kernel_config(request, monkeypatch):
+    """Every case runs under the library's own choice of kernel and under each forced one:
+    0 = 4 waves / 128-row tiles, 1 = 8 waves / 256-row tiles, 2 = the phase-locked 8-wave kernel."""
+    if request.param == "auto":
+        monkeypatch.delenv("LV_PREFILL_CFG", raising=False)
+    else:
+        monkeypatch.setenv("LV_PREFILL_CFG", request.param)
+    return request.param
+
+
 def _run(gpu, case):
     from light_vllm_amd import ops
     d = to_dev(case, gpu)
@@ -110,3 +121,21 @@ def test_prefill_matches_decode_last_row(gpu):
                                d["block_table"], d["scale"])
     torch.cuda.synchronize()
     assert (out[-1:].float() - dec.float()).abs().max().item() <= 1e-2
+
+
+def test_prefill_odd_tile_counts(gpu):
+    """Tile counts 1..5 per 256-row query tile, partial last tiles, and a sequence longer than 2048
+    (the length from which the library picks the phase-locked kernel on its own)."""
+    lens = [64, 65, 128, 129, 192, 257, 320, 2049 + 77]
+    _check(gpu, make_prefill_case(29, lens, lens, 16, 8))
+
+
+def test_prefill_spiked_scores_long(gpu):
+    """Running-max rescale late in a long sequence, in both 32-key halves of a tile and in the
+    last tile of a row block."""
+    L = 2304
+    case = make_prefill_case(30, [L], [L], 8, 1)
+    case["k"][2000, 0] = (case["q"][2100, 1].float() * 4.0).to(torch.bfloat16)
+    case["k"][2000 + 40, 0] = (case["q"][2200, 5].float() * 5.0).to(torch.bfloat16)
+    case["k"][2303, 0] = (case["q"][2303, 7].float() * 6.0).to(torch.bfloat16)
+    _check(gpu, case)

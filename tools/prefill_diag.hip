@@ -77,6 +77,8 @@ int main(int argc, char** argv) {
                               "barrier after C_PV", "L_V: K publish + loads", "L_V: V reads (+wait)", "L_K: V publish + loads", "L_K: K reads (+wait)", "-", "-", "-", "-"};
   const char* cfg = getenv("LV_PREFILL_CFG");
   if (cfg && atoi(cfg) == 2) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
+  if (seg[13] > 0) printf("in-kernel clock: %.0f MHz (shader ticks per 100 MHz reference tick, averaged over waves)\n", 100.0 * seg[12] / seg[13]);
+  tot -= seg[12] + seg[13]; seg[12] = seg[13] = 0;
   tot -= seg[15];
   for (int i = 0; i < 15; ++i)
     if (seg[i] > 0) printf("%-34s %6.2f %%   %8.0f ticks per (wave, tile)\n", names[i], 100.0 * seg[i] / tot, seg[i] / seg[15]);
