@@ -41,6 +41,20 @@ def test_config1_teacher_forced_parity(gpu, enforce_eager):
     assert len(soft) <= compared // 20, f"too many tie flips: {soft}"
 
 
+def test_config1_256_decode_steps(gpu):
+    """The same four prompts carried through 256 decode steps (sequences grow from 256 to 512
+    tokens and take a second KV block), hipGraph decode, teacher-forced and tie-aware as above."""
+    golden = load_golden("e2e_config1_256.json")
+    cfg, runner, sch = _parts(golden, enforce_eager=False)
+    compared, soft, hard, max_dev = replay(golden, runner, sch, tie_ulps=TIE_ULPS)
+    print(f"compared {compared} tokens, max top-5 logit deviation {max_dev:.4f}, {len(soft)} tie flips, hard mismatches {hard}")
+    runner.exit()
+    assert compared == 4 * 256
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert max_dev <= MAX_LOGIT_DEV, f"logit deviation {max_dev}"
+    assert len(soft) <= compared // 20, f"too many tie flips: {soft}"
+
+
 def test_generate_free_running(gpu):
     """LLM.generate (free running, hipGraph decode): every sequence must follow the reference
     completion at least up to the first step where the reference itself was tied (is_tie)."""
