@@ -15,6 +15,8 @@
 //     (fp32 workspace + a small merge kernel) with the usual (m, l) rescaling rule;
 //   * the grid depends only on static shapes (batch, kv heads, splits); each workgroup derives
 //     its token range from context_lens on device, so the launch is hipGraph-replay safe.
+#include <stdlib.h>
+
 #include "lv_kernels.h"
 
 namespace lv {
@@ -259,6 +261,239 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core variant for wide query groups (G = 8, optionally 4). With 8 query heads per kv
+// head the vector-ALU formulation above spends ~170 instructions per 1 KiB loaded and is
+// ALU-bound; here both products run on v_mfma_f32_16x16x32_bf16 with the G heads padded to the
+// 16-wide dimension:
+//   S^T[key][head] = K[key][:] Q^T      A = K rows straight from global memory (a lane's 16-byte
+//                                       load IS its A fragment: row = key, 8 consecutive d),
+//                                       B = Q^T fragments held in registers
+//   O^T[d][head]  += V^T[d][key] P^T    A = V^T via ds_read_b64_tr_b16 from a wave-private LDS
+//                                       image of the V rows, B = the bf16-rounded P registers
+// The score tile has the head on the lane and 4 keys in registers, so the softmax statistics are
+// in-register plus two row exchanges, and P needs no lane movement to become the B operand.
+// Wave chunk = 32 keys (two 16-key score tiles = one 32-deep k-step of the second product).
+// A-operand row i of a score tile holds key pi(i) = 8*((i>>2)&1) + 4*(i>>3) + (i&3) of the tile, so
+// that the two 16-lane groups of a 32-lane half read V blocks 8 rows apart (bank-conflict free).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+
+__device__ __forceinline__ int v_lds_off(int row, int ch) {  // [rows][128 x bf16] image, 16-byte chunks swizzled
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams p) {
+  constexpr int CH = 32;  // keys per wave chunk
+  constexpr float kDefer = 6.0f;  // running max moves only when a row outgrows it by 2^6
+  // per wave: 8 KiB V image during the sweep; afterwards per wave G x (128 + 2) floats of partials
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 8192];
+  lds_byte_t* const lds3 = (lds_byte_t*)lds;
+
+  const int nsplit = p.nsplit;
+  const int Hkv = p.num_kv_heads;
+  const int bid = blockIdx.x;
+  const int split = bid % nsplit;
+  const int bk = bid / nsplit;
+  const int b = bk % p.batch;
+  const int kvh = bk / p.batch;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int c16 = lane & 15;  // MFMA row (A) / column (B, C): head index for B and C
+  const int q = lane >> 4;    // 8-element k group of A/B, 4-row group of C
+
+  const int BS = p.block_size;
+  const int ctx = p.context_lens[b];
+  const int nunits = (ctx + kSplitUnit - 1) / kSplitUnit;
+  const int ulo = static_cast<int>(static_cast<int64_t>(split) * nunits / nsplit);
+  const int uhi = static_cast<int>(static_cast<int64_t>(split + 1) * nunits / nsplit);
+  const int t0 = ulo * kSplitUnit;
+  const int t1 = min(uhi * kSplitUnit, ctx);
+  const int ntok = t1 - t0;
+  const int nchunks = ntok > 0 ? (ntok + CH - 1) / CH : 0;
+  const int64_t row_bytes = static_cast<int64_t>(Hkv) * kHeadDim * 2;
+  const int32_t* bt_row = p.block_table + static_cast<int64_t>(b) * p.bt_stride;
+
+  // Q^T fragments (B operand), k-step s covers d = 32s .. 32s+31; heads >= G are zero columns
+  bf16x8_t qf[4];
+  {
+    const int hq = kvh * G + min(c16, G - 1);
+    const uint16_t* qp = p.q + static_cast<int64_t>(b) * p.q_stride0 + hq * kHeadDim + 8 * q;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(qp + 32 * s);
+      if (c16 >= G) t = u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(bf16x8_t, t);
+    }
+  }
+
+  // which key of a 16-key tile this lane's A row holds / this lane's C registers hold
+  const int a_key = 8 * ((c16 >> 2) & 1) + 4 * (c16 >> 3) + (c16 & 3);
+  const int c_key0 = 8 * (q & 1) + 4 * (q >> 1);  // + r for register r
+
+  // V staging: lane loads chunk (lane & 15) of rows 4u + q (u = 0..7) and stores it swizzled
+  lds_byte_t* const vimg = lds3 + wave * 8192;
+  const int vw_off = v_lds_off(q, c16);          // row 4u + q: + 1024 * u, chunk index ^ (u & 3)
+  // transposed reads: lane 4q''+p'' of a group addresses row r0 + q'', columns 4p'' .. of block dt
+  const int tq = c16 >> 2, tp = c16 & 3;
+  const int vr_row = c_key0 + tq;                // second read: + 16 rows
+  // byte offset for dt = 0; block dt adds chunk 2*dt, which XORs into the swizzled chunk index
+  int vr_off[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) vr_off[t] = v_lds_off(vr_row + 16 * t, tp >> 1) + 8 * (tp & 1);
+
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = p.scale_log2e;
+
+  auto chunk_row = [&](int c) -> int64_t {  // cache row of the chunk's first key
+    const int t = t0 + c * CH;
+    const int blk = bt_row[t / BS];
+    return static_cast<int64_t>(blk) * BS + (t % BS);
+  };
+  u32x4 kreg[2][4], vreg[8];
+  auto issue_k = [&](int c) {
+    const char* base = reinterpret_cast<const char*>(p.k_cache) + chunk_row(c) * row_bytes + kvh * (kHeadDim * 2);
+    const int last = ntok - 1 - c * CH;  // rows past the split's end re-read its last row (masked below)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const char* rp = base + static_cast<int64_t>(min(16 * t + a_key, last)) * row_bytes + 16 * q;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kreg[t][s] = load16<true>(reinterpret_cast<const uint16_t*>(rp + 64 * s));
+    }
+  };
+  auto issue_v = [&](int c) {
+    const char* base = reinterpret_cast<const char*>(p.v_cache) + chunk_row(c) * row_bytes + kvh * (kHeadDim * 2) + 16 * c16;
+    const int last = ntok - 1 - c * CH;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      vreg[u] = load16<true>(reinterpret_cast<const uint16_t*>(base + static_cast<int64_t>(min(4 * u + q, last)) * row_bytes));
+  };
+
+  int c = wave;
+  if (c < nchunks) {
+    issue_k(c);
+    issue_v(c);
+  }
+  for (; c < nchunks; c += 4) {
+    const int cn = c + 4;
+    // ---- S^T = K Q^T for the two 16-key tiles
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kreg[0][s]), qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kreg[1][s]), qf[s], s1, 0, 0, 0);
+    }
+    if (cn < nchunks) issue_k(cn);
+    // ---- scale, mask keys past the split's end, row maximum over the chunk's 32 keys
+    const int valid = ntok - c * CH;
+    float sv[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sv[r] = (c_key0 + r < valid) ? s0[r] * sc : -INFINITY;
+      sv[4 + r] = (16 + c_key0 + r < valid) ? s1[r] * sc : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // deferred running-max update (wave-uniform decision)
+    if (__builtin_amdgcn_ballot_w64(mx - m_run > kDefer || (m_run == -INFINITY && mx > -INFINITY)) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_run == -INFINITY) ? 0.f : fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+    float pe[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pe[j] = fast_exp2(sv[j] - m_use);
+      l_run += pe[j];
+    }
+    bf16x8_t pf;  // k slot (q, j): j < 4 -> tile 0 register j, j >= 4 -> tile 1 register j-4
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = static_cast<__bf16>(pe[j]);
+    // ---- V rows -> LDS image (wave private: same-wave LDS operations execute in order)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(vimg + ((vw_off ^ (16 * (u & 3))) + 1024 * u)) = vreg[u];
+    if (cn < nchunks) issue_v(cn);
+    // ---- O^T += V^T P^T, one 16-column block of d per MFMA
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      bf16x8_t va;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            reinterpret_cast<__attribute__((address_space(3))) bf16x4_t*>(vimg + (vr_off[t] ^ (32 * dt))));
+        va[4 * t + 0] = x[0];
+        va[4 * t + 1] = x[1];
+        va[4 * t + 2] = x[2];
+        va[4 * t + 3] = x[3];
+      }
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf, oacc[dt], 0, 0, 0);
+    }
+  }
+
+  // ---- row sums: every 16-lane group holds a share
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+
+  // ---- merge the 4 waves through LDS: per wave [G][128] partial outputs + (m, l)
+  __syncthreads();   // all waves are done with their V images
+  float* const part = reinterpret_cast<float*>(lds);
+  constexpr int kPartStride = G * kHeadDim + 2 * G;  // floats per wave
+  if (c16 < G) {
+    float* dst = part + wave * kPartStride + c16 * kHeadDim;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(dst + 16 * dt + 4 * q) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+    if (q == 0) {
+      part[wave * kPartStride + G * kHeadDim + 2 * c16 + 0] = m_run;
+      part[wave * kPartStride + G * kHeadDim + 2 * c16 + 1] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < G * kHeadDim; e += 256) {
+    const int h = e / kHeadDim;
+    const int d = e % kHeadDim;
+    float M = part[G * kHeadDim + 2 * h];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, part[w * kPartStride + G * kHeadDim + 2 * h]);
+    const float Mu = (M == -INFINITY) ? 0.f : M;
+    float val = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = fast_exp2(part[w * kPartStride + G * kHeadDim + 2 * h] - Mu);
+      val += f * part[w * kPartStride + h * kHeadDim + d];
+      L += f * part[w * kPartStride + G * kHeadDim + 2 * h + 1];
+    }
+    const int hq = kvh * G + h;
+    if (nsplit == 1) {
+      const float r = L > 0.f ? val / L : 0.f;
+      p.o[static_cast<int64_t>(b) * p.o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
+    } else {
+      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * nsplit + split;
+      p.ws_o[slot * kHeadDim + d] = val;
+      if (d == 0) {
+        p.ws_ml[slot * 2 + 0] = M;
+        p.ws_ml[slot * 2 + 1] = L;
+      }
+    }
+  }
+}
+
 // Combine the nsplit partial results of one (sequence, query head). 256 lanes = 8 groups of 32;
 // a lane owns 4 output dims (one 16-byte load per split) and its group walks splits g, g+8, ...,
 // so many independent loads are in flight; groups are merged through LDS.
@@ -321,13 +556,25 @@ static void launch_g(const DecodeParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((decode_attn_kernel<G, U, true>), dim3(grid), dim3(256), 0, stream, p);
 }
 
+template <int G>
+static void launch_mfma(const DecodeParams& p, hipStream_t stream) {
+  const unsigned grid = static_cast<unsigned>(p.batch) * p.num_kv_heads * p.nsplit;
+  hipLaunchKernelGGL((decode_mfma_kernel<G>), dim3(grid), dim3(256), 0, stream, p);
+}
+
 int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
   const int G = p.num_heads / p.num_kv_heads;
+  // Kernel choice: the matrix-core kernel for 4 and 8 query heads per kv head, the vector-ALU
+  // kernel for 1 and 2. LV_DECODE_MFMA=0 / 1 forces one of them for every group size (read on
+  // every call: tests switch it).
+  const char* env = getenv("LV_DECODE_MFMA");
+  const int force = env ? atoi(env) : -1;
+  const bool mfma = force >= 0 ? force != 0 : G >= 4;
   switch (G) {
-    case 1: launch_g<1, 8>(p, stream); break;
-    case 2: launch_g<2, 8>(p, stream); break;
-    case 4: launch_g<4, 4>(p, stream); break;
-    case 8: launch_g<8, 4>(p, stream); break;
+    case 1: if (mfma) launch_mfma<1>(p, stream); else launch_g<1, 8>(p, stream); break;
+    case 2: if (mfma) launch_mfma<2>(p, stream); else launch_g<2, 8>(p, stream); break;
+    case 4: if (mfma) launch_mfma<4>(p, stream); else launch_g<4, 4>(p, stream); break;
+    case 8: if (mfma) launch_mfma<8>(p, stream); else launch_g<8, 4>(p, stream); break;
     default:
       return fail(LV_ERR_UNSUPPORTED, "decode: num_heads/num_kv_heads = %d not in {1,2,4,8}", G);
   }

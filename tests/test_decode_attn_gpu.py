@@ -92,3 +92,38 @@ def test_decode_config2_shape_properties(gpu):
     sub = {k: (v[rows] if k in ("q", "context_lens", "block_table") else v) for k, v in case.items()}
     ref = decode_ref(sub["q"], sub["k_cache"], sub["v_cache"], sub["context_lens"], sub["block_table"], sub["scale"])
     assert (out[rows].float().cpu() - ref).abs().max().item() <= TOL
+
+
+# ---- The library picks the matrix-core kernel for 4 and 8 query heads per kv head and the
+# ---- vector-ALU kernel for 1 and 2; LV_DECODE_MFMA=0 / 1 forces one of them for every group size.
+@pytest.mark.parametrize("mfma", ["0", "1"])
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (64, 8), (16, 2), (4, 1), (32, 8), (16, 8), (8, 8)])
+def test_decode_wide_groups_both_kernels(gpu, monkeypatch, Hq, Hkv, mfma):
+    monkeypatch.setenv("LV_DECODE_MFMA", mfma)
+    lens = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1024, 700]
+    _check(gpu, make_decode_case(12, lens, Hq, Hkv))
+
+
+@pytest.mark.parametrize("num_splits", [1, 2, 3, 8, 0])
+def test_decode_wide_groups_split_kv(gpu, num_splits):
+    lens = [2048, 1, 513, 1500, 256]
+    _check(gpu, make_decode_case(13, lens, 8, 1, pad_cols=2), num_splits=num_splits)
+    _check(gpu, make_decode_case(14, lens, 64, 8, pad_cols=1), num_splits=num_splits)
+
+
+def test_decode_wide_groups_zero_rows_spikes_block64(gpu):
+    case = make_decode_case(15, [300, 40], 64, 8)
+    case["context_lens"] = torch.tensor([300, 0], dtype=torch.int32)
+    case["block_table"][1] = 0
+    out = _check(gpu, case)
+    assert out[1].abs().sum().item() == 0
+    out = _check(gpu, case, num_splits=2)
+    assert out[1].abs().sum().item() == 0
+    case = make_decode_case(16, [1024, 777], 8, 1)
+    bt = case["block_table"]
+    for b, t, hq in ((0, 900, 0), (1, 776, 5), (0, 40, 7)):
+        blk = int(bt[b, t // 256])
+        case["k_cache"][blk, t % 256, 0] = (case["q"][b, hq].float() * 4.0).to(torch.bfloat16)
+    _check(gpu, case)
+    _check(gpu, case, num_splits=4)
+    _check(gpu, make_decode_case(17, [100, 64, 65, 1], 8, 1, block_size=64))
