@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 2
+#define LV_ABI_VERSION 3
 
 typedef void* lv_stream_t;
 
@@ -135,6 +135,12 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
  *   num_splits    KV splits per (sequence, kv head): 0 = library heuristic
  *                 (lv_decode_num_splits), 1 = single pass, n > 1 = split-KV with a merge
  *                 pass through `workspace` (>= lv_decode_workspace_bytes bytes, 16-byte aligned).
+ *   seq_order     optional int32 [batch] permutation of 0..batch-1 (NULL = identity): the order
+ *                 in which sequences are handed to the GPU. Passing the sequences longest first
+ *                 evens out the tail of a ragged batch; results do not depend on it. Entries
+ *                 outside [0, batch) are skipped (that sequence's output is then not written).
+ *                 No counterpart in the reference call; a caller that has no lengths on the
+ *                 host passes NULL.
  *
  * bf16 inputs, fp32 scores / online softmax / accumulation, bf16 output.
  */
@@ -145,7 +151,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    int batch, int max_blocks_per_seq, int block_size,
                    int num_heads, int num_kv_heads, int head_dim, float scale,
                    void* workspace, size_t workspace_bytes, int num_splits,
-                   lv_stream_t stream);
+                   const int32_t* seq_order, lv_stream_t stream);
 
 #ifdef __cplusplus
 }

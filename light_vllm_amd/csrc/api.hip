@@ -144,7 +144,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    const int32_t* block_table, int block_table_stride, int batch,
                    int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
                    int head_dim, float scale, void* workspace, size_t workspace_bytes,
-                   int num_splits, lv_stream_t stream) {
+                   int num_splits, const int32_t* seq_order, lv_stream_t stream) {
   if (batch < 0 || max_blocks_per_seq < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_splits < 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "decode: head_dim %d != 128", head_dim);
@@ -184,6 +184,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
   }
   p.context_lens = context_lens;
   p.block_table = block_table;
+  p.seq_order = seq_order;
   p.q_stride0 = q_stride0;
   p.o_stride0 = o_stride0;
   p.bt_stride = block_table_stride;

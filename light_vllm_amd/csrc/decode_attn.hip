@@ -51,8 +51,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
   const int bid = blockIdx.x;
   const int split = bid % nsplit;
   const int bk = bid / nsplit;
-  const int b = bk % p.batch;
+  const int bi = bk % p.batch;
+  const int b = p.seq_order ? p.seq_order[bi] : bi;   // caller-chosen launch order (longest first)
   const int kvh = bk / p.batch;
+  if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,8 +300,10 @@ __global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams 
   const int bid = blockIdx.x;
   const int split = bid % nsplit;
   const int bk = bid / nsplit;
-  const int b = bk % p.batch;
+  const int bi = bk % p.batch;
+  const int b = p.seq_order ? p.seq_order[bi] : bi;   // caller-chosen launch order (longest first)
   const int kvh = bk / p.batch;
+  if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -14,6 +14,7 @@ struct DecodeParams {
   float* ws_ml;  // [batch, Hq, nsplit, 2]   (running max in log2 units, sum)
   const int32_t* context_lens;
   const int32_t* block_table;
+  const int32_t* seq_order;  // optional launch order of the sequences (nullptr = identity)
   int64_t q_stride0, o_stride0;
   int bt_stride, batch, block_size, num_heads, num_kv_heads, nsplit;
   float scale_log2e;

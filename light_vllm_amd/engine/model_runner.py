@@ -243,7 +243,12 @@ class ModelRunner:
         slot_mapping = self._to_device(slot_mapping, torch.int32)
         context_lens = self._to_device(context_lens, torch.int32)
         block_tables = self.prepare_block_tables(seqs)
-        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
+        # launch order for the decode kernel: longest sequences first (stable), so a ragged batch
+        # does not end on a long straggler; the host already has the lengths
+        order = sorted(range(len(seqs)), key=lambda j: -len(seqs[j]))
+        seq_order = self._to_device(order, torch.int32)
+        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables,
+                    seq_order=seq_order)
         return input_ids, positions
 
     def prepare_sample(self, seqs: list[Sequence]) -> torch.Tensor:
@@ -268,6 +273,8 @@ class ModelRunner:
         gv["slot_mapping"][:bs] = context.slot_mapping
         gv["context_lens"][:bs] = context.context_lens
         gv["block_tables"][:bs, :context.block_tables.size(1)] = context.block_tables
+        gv["seq_order"][:bucket] = self._iota[:bucket]     # padding rows keep their own index ...
+        gv["seq_order"][:bs] = context.seq_order           # ... behind the real rows, longest first
         self.graphs[bucket].replay()
         return self.model.compute_logits(gv["outputs"][:bs])
 
@@ -294,6 +301,8 @@ class ModelRunner:
         context_lens = torch.zeros(max_bs, dtype=torch.int32, device=dev)
         block_tables = torch.zeros(max_bs, max_num_blocks, dtype=torch.int32, device=dev)
         outputs = torch.zeros(max_bs, hf.hidden_size, dtype=self.dtype, device=dev)
+        self._iota = torch.arange(max_bs, dtype=torch.int32, device=dev)
+        seq_order = self._iota.clone()
         self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
         self.graphs = {}
         self.graph_pool = None
@@ -308,7 +317,7 @@ class ModelRunner:
         for bs in reversed(self.graph_bs):
             graph = torch.cuda.CUDAGraph()
             set_context(False, slot_mapping=slot_mapping[:bs], context_lens=context_lens[:bs],
-                        block_tables=block_tables[:bs])
+                        block_tables=block_tables[:bs], seq_order=seq_order[:bs])
             outputs[:bs] = self.model(input_ids[:bs], positions[:bs])   # warm run outside capture
             with torch.cuda.graph(graph, pool=self.graph_pool):
                 outputs[:bs] = self.model(input_ids[:bs], positions[:bs])
@@ -318,4 +327,5 @@ class ModelRunner:
             torch.cuda.synchronize()
             reset_context()
         self.graph_vars = dict(input_ids=input_ids, positions=positions, slot_mapping=slot_mapping,
-                               context_lens=context_lens, block_tables=block_tables, outputs=outputs)
+                               context_lens=context_lens, block_tables=block_tables, outputs=outputs,
+                               seq_order=seq_order)

@@ -48,5 +48,5 @@ class Attention(nn.Module):
                                       block_table=context.block_tables)
         else:
             o = ops.decode_attention(q, k_cache, v_cache, context.context_lens,
-                                     context.block_tables, self.scale)
+                                     context.block_tables, self.scale, seq_order=context.seq_order)
         return o.view(-1, self.num_heads * self.head_dim)

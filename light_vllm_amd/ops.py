@@ -146,12 +146,15 @@ def _workspace(device: torch.device, nbytes: int) -> Tuple[Optional[int], int, O
 
 def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                      context_lens: torch.Tensor, block_table: torch.Tensor, softmax_scale: float,
-                     num_splits: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     num_splits: int = 0, out: Optional[torch.Tensor] = None,
+                     seq_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One query token per sequence over the paged cache.
 
     q: [B, Hq, D]; caches [num_blocks, block_size, Hkv, D] contiguous; context_lens int32 [B]
     (already counting the token stored this step); block_table int32 [B, max_blocks].
     num_splits: 0 = library heuristic, 1 = single pass, n = split-KV + merge.
+    seq_order: optional int32 [B] permutation, the order sequences are launched in (longest first
+    evens out ragged batches); the result does not depend on it.
     """
     dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
     B, Hq, D = q.shape
@@ -165,6 +168,9 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     assert block_table.dtype == torch.int32 and block_table.dim() == 2 and block_table.stride(1) == 1
     assert block_table.size(0) == B
     max_blocks = block_table.size(1)
+    if seq_order is not None:
+        assert seq_order.dtype == torch.int32 and seq_order.is_contiguous() and seq_order.numel() == B
+        assert seq_order.device == q.device
     if out is None:
         out = torch.empty((B, Hq, D), dtype=_BF16, device=dev)
     else:
@@ -179,6 +185,7 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                                 q.stride(0), out.stride(0), context_lens.data_ptr(),
                                 block_table.data_ptr(), block_table.stride(0), B, max_blocks, block_size,
                                 Hq, Hkv, D, float(softmax_scale), ws_ptr, ws_bytes, nsplit,
+                                seq_order.data_ptr() if seq_order is not None else None,
                                 _stream_ptr(dev))
     _lib.check(rc, "lv_decode_attn")
     del keep

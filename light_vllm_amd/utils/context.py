@@ -2,7 +2,8 @@
 
 Same contract as the reference's lightvllm/utils/context.py:15-75: a module-global dataclass that
 `set_context` replaces wholesale before each forward pass and `reset_context` clears after it.
-Field order and defaults match so positional `set_context(...)` calls behave identically.
+Field order and defaults match so positional `set_context(...)` calls behave identically; the one
+extra field, `seq_order`, comes last and defaults to None.
 Not thread-safe, by design of the contract (one Python thread per rank process).
 """
 from __future__ import annotations
@@ -23,6 +24,7 @@ class Context:
     slot_mapping: Optional[torch.Tensor] = None   # int32 [N]
     context_lens: Optional[torch.Tensor] = None   # int32 [B], decode only
     block_tables: Optional[torch.Tensor] = None   # int32 [B, max_blocks], -1 padded
+    seq_order: Optional[torch.Tensor] = None      # int32 [B], decode only: launch order, longest first
 
 
 _CONTEXT = Context()
@@ -33,10 +35,10 @@ def get_context() -> Context:
 
 
 def set_context(is_prefill, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0, max_seqlen_k=0,
-                slot_mapping=None, context_lens=None, block_tables=None) -> None:
+                slot_mapping=None, context_lens=None, block_tables=None, seq_order=None) -> None:
     global _CONTEXT
     _CONTEXT = Context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-                       slot_mapping, context_lens, block_tables)
+                       slot_mapping, context_lens, block_tables, seq_order)
 
 
 def reset_context() -> None:

@@ -19,7 +19,8 @@ def _prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, so
     return orc.prefill_ref(q, k, v, cu_seqlens_q, cu_seqlens_k, softmax_scale, block_table).to(q.dtype)
 
 
-def _decode(q, k_cache, v_cache, context_lens, block_table, softmax_scale, num_splits=0, out=None):
+def _decode(q, k_cache, v_cache, context_lens, block_table, softmax_scale, num_splits=0, out=None,
+            seq_order=None):
     return orc.decode_ref(q, k_cache, v_cache, context_lens, block_table, softmax_scale).to(q.dtype)
 
 

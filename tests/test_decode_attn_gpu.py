@@ -127,3 +127,30 @@ def test_decode_wide_groups_zero_rows_spikes_block64(gpu):
     _check(gpu, case)
     _check(gpu, case, num_splits=4)
     _check(gpu, make_decode_case(17, [100, 64, 65, 1], 8, 1, block_size=64))
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (8, 1)])
+def test_decode_seq_order_does_not_change_results(gpu, Hq, Hkv):
+    """seq_order only changes which workgroup serves which sequence: outputs are bit-identical for
+    the identity, longest-first and a random permutation; an out-of-range entry skips that row."""
+    from light_vllm_amd import ops
+    lens = [5, 1024, 33, 700, 256, 1, 999, 64]
+    case = make_decode_case(18, lens, Hq, Hkv)
+    d = to_dev(case, gpu)
+    args = (d["q"], d["k_cache"], d["v_cache"], d["context_lens"], d["block_table"], d["scale"])
+    base = ops.decode_attention(*args)
+    B = len(lens)
+    longest_first = sorted(range(B), key=lambda j: -lens[j])
+    g = torch.Generator().manual_seed(3)
+    for order in (list(range(B)), longest_first, torch.randperm(B, generator=g).tolist()):
+        so = torch.tensor(order, dtype=torch.int32, device=gpu)
+        for ns in (0, 1, 3):
+            out = ops.decode_attention(*args, num_splits=ns, seq_order=so)
+            ref = base if ns == 0 else ops.decode_attention(*args, num_splits=ns)
+            assert torch.equal(out, ref)
+    so = torch.tensor([0, 1, 2, 3, 4, 5, 6, 99], dtype=torch.int32, device=gpu)
+    out = torch.full_like(base, 7.0)
+    ops.decode_attention(*args, num_splits=1, out=out, seq_order=so)
+    torch.cuda.synchronize()
+    ref = ops.decode_attention(*args, num_splits=1)
+    assert torch.equal(out[:7], ref[:7]) and bool((out[7] == 7.0).all())

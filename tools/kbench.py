@@ -29,7 +29,7 @@ def timeit(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False):
+def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False):
     bps = (ctx + BLOCK - 1) // BLOCK
     nblk = B * bps
     # several distinct caches so the working set exceeds the 256 MiB Infinity Cache
@@ -44,19 +44,21 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False):
         lens = torch.full((B,), ctx, dtype=torch.int32)
     ctx_t = lens.to(dev)
     out = torch.empty_like(q)
+    # launch order: longest first, as ModelRunner.prepare_decode passes it
+    order = torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(dev) if ordered else None
     state = {"i": 0}
 
     def fn():
         l = state["i"] % layers
         state["i"] += 1
-        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out)
+        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out, seq_order=order)
 
     t = timeit(fn)
     tot = int(lens.sum())
     nb = int(((lens + BLOCK - 1) // BLOCK).sum())
     bytes_ = tot * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nb
     ns = nsplit or ops.decode_num_splits(B, Hkv, bps, BLOCK)
-    return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, us=round(t * 1e6, 1),
+    return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, ordered=ordered, us=round(t * 1e6, 1),
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
 
@@ -86,6 +88,9 @@ def main():
         for (Hq, Hkv) in [(16, 8), (32, 8), (64, 8)]:
             rows.append(decode_case(256, 1024, Hq, Hkv))
         rows.append(decode_case(256, 1024, 32, 8, ragged=True))
+        rows.append(decode_case(256, 1024, 32, 8, ragged=True, ordered=True))
+        rows.append(decode_case(256, 1024, 16, 8, ragged=True))
+        rows.append(decode_case(256, 1024, 16, 8, ragged=True, ordered=True))
         rows.append(decode_case(64, 4096, 32, 8))
         for (Hq, Hkv) in [(16, 4), (8, 2), (4, 1), (8, 1)]:
             for B in (1, 8, 64):
