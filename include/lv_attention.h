@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 3
+#define LV_ABI_VERSION 4
 
 typedef void* lv_stream_t;
 
@@ -72,6 +72,63 @@ int lv_store_kvcache(const void* key, const void* value,
                      const int32_t* slot_mapping,
                      int64_t num_tokens, int num_kv_heads, int head_dim,
                      int64_t num_slots, lv_stream_t stream);
+
+/*
+ * The step in front of the attention call, fused with the cache store: per-head RMSNorm of q and
+ * k, neox rotary embedding of both, then the K/V scatter of lv_store_kvcache.
+ * Reference: Qwen3Attention.forward, models/qwen3.py:100-113 (q_norm / k_norm :100-106,
+ * rotary_emb :109, store inside self.attn :113 -> attention.py:149-150); arithmetic and rounding
+ * points of layers/layernorm.py:39-50 and layers/rotary_embedding.py:33-42:
+ *
+ *   for every head x of q (weight q_weight) and of k (weight k_weight), in fp32:
+ *       n = bf16( bf16( x * rsqrt(mean(x^2) + eps) ) * weight )
+ *       y[0:64]   = bf16( n[0:64] * cos - n[64:128] * sin )
+ *       y[64:128] = bf16( n[64:128] * cos + n[0:64] * sin )      cos, sin = cos_sin_cache[positions[i]]
+ *   q and k are overwritten with y; k_cache[slot_mapping[i]] = k[i] (after rotation),
+ *   v_cache[slot_mapping[i]] = value[i].
+ *
+ *   q [num_tokens, num_heads, 128], k, v [num_tokens, num_kv_heads, 128]: row strides free (all
+ *   three are normally views into one fused qkv activation), last two dims contiguous.
+ *   positions      int64 [num_tokens]; clamped into [0, max_position).
+ *   q_weight, k_weight  bf16 [128].
+ *   cos_sin_cache  fp32 [max_position, 128]: 64 cosines then 64 sines per position
+ *                  (rotary_embedding.py:76-91).
+ *   k_cache, v_cache, slot_mapping, num_slots: as lv_store_kvcache; pass all three pointers NULL
+ *                  to skip the store (the reference skips it while the caches are unallocated,
+ *                  attention.py:149).
+ * Products and sums are evaluated unfused, in the reference's order; only the summation order of
+ * the mean of squares is the library's own.
+ */
+int lv_qk_norm_rope_store(void* q, void* k, const void* v,
+                          int64_t q_stride0, int64_t k_stride0, int64_t v_stride0,
+                          const int64_t* positions, const void* q_weight, const void* k_weight,
+                          float eps, const float* cos_sin_cache, int64_t max_position,
+                          void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                          int64_t num_slots, int64_t num_tokens,
+                          int num_heads, int num_kv_heads, int head_dim, lv_stream_t stream);
+
+/*
+ * RMSNorm with optional residual add, the normalisation either side of the attention block.
+ * Reference: RMSNorm.rms_forward / add_rms_forward, layers/layernorm.py:28-80.
+ *
+ *   residual == NULL:  out = bf16( bf16( x * rsqrt(mean(x^2) + eps) ) * weight )
+ *   residual != NULL:  s = fp32(x) + fp32(residual);  residual = bf16(s)   (updated in place)
+ *                      out = bf16( bf16( s * rsqrt(mean(s^2) + eps) ) * weight )
+ *
+ *   x, out [num_tokens, hidden_size] (out may alias x), residual [num_tokens, hidden_size],
+ *   weight bf16 [hidden_size]; hidden_size a multiple of 8, at most 8192.
+ */
+int lv_add_rms_norm(const void* x, void* residual, const void* weight, void* out,
+                    int64_t x_stride0, int64_t residual_stride0, int64_t out_stride0,
+                    int64_t num_tokens, int hidden_size, float eps, lv_stream_t stream);
+
+/*
+ * out = bf16( bf16(silu(gate)) * up ) with gate = x[:, :intermediate_size], up = x[:, intermediate_size:].
+ * Reference: silu_and_mul_native, layers/activation.py:7-29.
+ *   x [num_tokens, 2 * intermediate_size], out [num_tokens, intermediate_size].
+ */
+int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_stride0,
+                    int64_t num_tokens, int intermediate_size, lv_stream_t stream);
 
 /*
  * Variable-length causal self-attention over a packed batch (prefill).

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvattn.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); must list every symbol include/lv_attention.h declares.
 SIGNATURES = {
@@ -21,6 +21,12 @@ SIGNATURES = {
     "lv_last_error": (c_char_p, []),
     "lv_store_kvcache": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_int, c_int, c_int64, c_void_p]),
+    "lv_qk_norm_rope_store": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "lv_add_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                c_int64, c_int, c_float, c_void_p]),
+    "lv_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "lv_prefill_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                 c_int, c_int, c_int, c_float, c_void_p]),

@@ -79,6 +79,90 @@ int lv_store_kvcache(const void* key, const void* value, int64_t key_stride0,
                               static_cast<hipStream_t>(stream));
 }
 
+int lv_qk_norm_rope_store(void* q, void* k, const void* v, int64_t q_stride0, int64_t k_stride0,
+                          int64_t v_stride0, const int64_t* positions, const void* q_weight,
+                          const void* k_weight, float eps, const float* cos_sin_cache,
+                          int64_t max_position, void* k_cache, void* v_cache,
+                          const int32_t* slot_mapping, int64_t num_slots, int64_t num_tokens,
+                          int num_heads, int num_kv_heads, int head_dim, lv_stream_t stream) {
+  if (num_tokens < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_slots < 0 || max_position <= 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "qk_norm_rope_store: negative size");
+  if (head_dim != kHeadDim)
+    return fail(LV_ERR_UNSUPPORTED, "qk_norm_rope_store: head_dim %d != 128", head_dim);
+  if (num_tokens == 0) return LV_OK;
+  if (!q || !k || !v || !positions || !q_weight || !k_weight || !cos_sin_cache)
+    return fail(LV_ERR_INVALID_ARGUMENT, "qk_norm_rope_store: null pointer");
+  const bool store = k_cache || v_cache || slot_mapping;
+  if (store && (!k_cache || !v_cache || !slot_mapping))
+    return fail(LV_ERR_INVALID_ARGUMENT,
+                "qk_norm_rope_store: k_cache, v_cache and slot_mapping must be given together");
+  const int64_t qrow = static_cast<int64_t>(num_heads) * head_dim;
+  const int64_t krow = static_cast<int64_t>(num_kv_heads) * head_dim;
+  if (q_stride0 < qrow || k_stride0 < krow || v_stride0 < krow)
+    return fail(LV_ERR_INVALID_ARGUMENT, "qk_norm_rope_store: row stride smaller than heads*head_dim");
+  if ((q_stride0 | k_stride0 | v_stride0) % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "qk_norm_rope_store: row strides must be multiples of 8 elements");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(q_weight) || !aligned16(k_weight) ||
+      !aligned16(cos_sin_cache) || !aligned16(k_cache) || !aligned16(v_cache))
+    return fail(LV_ERR_UNSUPPORTED, "qk_norm_rope_store: pointers must be 16-byte aligned");
+  QkNormRopeParams p;
+  p.q = static_cast<uint16_t*>(q);
+  p.k = static_cast<uint16_t*>(k);
+  p.v = static_cast<const uint16_t*>(v);
+  p.q_stride0 = q_stride0;
+  p.k_stride0 = k_stride0;
+  p.v_stride0 = v_stride0;
+  p.positions = positions;
+  p.q_weight = static_cast<const uint16_t*>(q_weight);
+  p.k_weight = static_cast<const uint16_t*>(k_weight);
+  p.cos_sin = cos_sin_cache;
+  p.max_position = max_position;
+  p.k_cache = store && num_slots > 0 ? static_cast<uint16_t*>(k_cache) : nullptr;
+  p.v_cache = store && num_slots > 0 ? static_cast<uint16_t*>(v_cache) : nullptr;
+  p.slot_mapping = store && num_slots > 0 ? slot_mapping : nullptr;
+  p.num_slots = num_slots;
+  p.num_tokens = num_tokens;
+  p.num_heads = num_heads;
+  p.num_kv_heads = num_kv_heads;
+  p.eps = eps;
+  return launch_qk_norm_rope_store(p, static_cast<hipStream_t>(stream));
+}
+
+int lv_add_rms_norm(const void* x, void* residual, const void* weight, void* out,
+                    int64_t x_stride0, int64_t residual_stride0, int64_t out_stride0,
+                    int64_t num_tokens, int hidden_size, float eps, lv_stream_t stream) {
+  if (num_tokens < 0 || hidden_size <= 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "add_rms_norm: negative size");
+  if (hidden_size % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "add_rms_norm: hidden_size %d is not a multiple of 8", hidden_size);
+  if (num_tokens == 0) return LV_OK;
+  if (!x || !weight || !out) return fail(LV_ERR_INVALID_ARGUMENT, "add_rms_norm: null pointer");
+  if (x_stride0 < hidden_size || out_stride0 < hidden_size || (residual && residual_stride0 < hidden_size))
+    return fail(LV_ERR_INVALID_ARGUMENT, "add_rms_norm: row stride smaller than hidden_size");
+  if ((x_stride0 | out_stride0 | (residual ? residual_stride0 : 0)) % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "add_rms_norm: row strides must be multiples of 8 elements");
+  if (!aligned16(x) || !aligned16(residual) || !aligned16(weight) || !aligned16(out))
+    return fail(LV_ERR_UNSUPPORTED, "add_rms_norm: pointers must be 16-byte aligned");
+  return launch_add_rms_norm(x, residual, weight, out, x_stride0, residual_stride0, out_stride0,
+                             num_tokens, hidden_size, eps, static_cast<hipStream_t>(stream));
+}
+
+int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_stride0,
+                    int64_t num_tokens, int intermediate_size, lv_stream_t stream) {
+  if (num_tokens < 0 || intermediate_size <= 0)
+    return fail(LV_ERR_INVALID_ARGUMENT, "silu_and_mul: negative size");
+  if (intermediate_size % 8 != 0)
+    return fail(LV_ERR_UNSUPPORTED, "silu_and_mul: intermediate_size %d is not a multiple of 8", intermediate_size);
+  if (num_tokens == 0) return LV_OK;
+  if (!x || !out) return fail(LV_ERR_INVALID_ARGUMENT, "silu_and_mul: null pointer");
+  if (x_stride0 < 2 * static_cast<int64_t>(intermediate_size) || out_stride0 < intermediate_size)
+    return fail(LV_ERR_INVALID_ARGUMENT, "silu_and_mul: row stride smaller than the row");
+  if ((x_stride0 | out_stride0) % 8 != 0 || !aligned16(x) || !aligned16(out))
+    return fail(LV_ERR_UNSUPPORTED, "silu_and_mul: 16-byte aligned pointers and strides %% 8 == 0 required");
+  return launch_silu_and_mul(x, out, x_stride0, out_stride0, num_tokens, intermediate_size,
+                             static_cast<hipStream_t>(stream));
+}
+
 int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_t q_stride0,
                     int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
                     const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,

@@ -33,10 +33,34 @@ struct PrefillParams {
   float scale_log2e;
 };
 
+struct QkNormRopeParams {
+  uint16_t* q;              // [N, Hq, 128], updated in place
+  uint16_t* k;              // [N, Hkv, 128], updated in place
+  const uint16_t* v;        // [N, Hkv, 128]
+  int64_t q_stride0, k_stride0, v_stride0;
+  const int64_t* positions; // [N]
+  const uint16_t* q_weight; // [128]
+  const uint16_t* k_weight; // [128]
+  const float* cos_sin;     // [max_position, 128]: cos (64) | sin (64)
+  int64_t max_position;
+  uint16_t* k_cache;        // nullable together with v_cache / slot_mapping: no store
+  uint16_t* v_cache;
+  const int32_t* slot_mapping;
+  int64_t num_slots, num_tokens;
+  int num_heads, num_kv_heads;
+  float eps;
+};
+
 int launch_store_kvcache(const void* key, const void* value, int64_t key_stride0,
                          int64_t value_stride0, void* k_cache, void* v_cache,
                          const int32_t* slot_mapping, int64_t num_tokens, int row_elems,
                          int64_t num_slots, hipStream_t stream);
+int launch_qk_norm_rope_store(const QkNormRopeParams& p, hipStream_t stream);
+int launch_add_rms_norm(const void* x, void* residual, const void* weight, void* out,
+                        int64_t x_stride0, int64_t res_stride0, int64_t out_stride0,
+                        int64_t num_tokens, int hidden, float eps, hipStream_t stream);
+int launch_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_stride0,
+                        int64_t num_tokens, int intermediate, hipStream_t stream);
 int launch_decode_attn(const DecodeParams& p, hipStream_t stream);
 int launch_prefill_attn(const PrefillParams& p, hipStream_t stream);
 

@@ -28,7 +28,10 @@ class Attention(nn.Module):
         self.k_cache = torch.tensor([])
         self.v_cache = torch.tensor([])
 
-    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                kv_stored: bool = False) -> torch.Tensor:
+        """kv_stored=True: the caller already scattered this step's K/V rows into the cache
+        (ops.qk_norm_rope_store does it in the same launch as the q/k normalisation and rotation)."""
         q = q.view(-1, self.num_heads, self.head_dim)
         k = k.view(-1, self.num_kv_heads, self.head_dim)
         v = v.view(-1, self.num_kv_heads, self.head_dim)
@@ -37,7 +40,7 @@ class Attention(nn.Module):
 
         # The store is stream-ordered before the attention launch below, so a prefix-cached
         # prefill and every decode step read the rows written here (reference :149-150).
-        if k_cache.numel() and v_cache.numel():
+        if not kv_stored and k_cache.numel() and v_cache.numel():
             store_kvcache(k, v, k_cache, v_cache, context.slot_mapping)
 
         if context.is_prefill:

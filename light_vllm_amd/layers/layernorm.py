@@ -6,6 +6,9 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from .. import ops
+from .fused import use_fused
+
 
 class RMSNorm(nn.Module):
 
@@ -31,6 +34,9 @@ class RMSNorm(nn.Module):
         return xf.to(dtype).mul_(self.weight), residual
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):
+        if use_fused(x):    # one HIP launch; the residual is updated in place
+            out = ops.add_rms_norm(x, residual, self.weight, self.eps)
+            return out if residual is None else (out, residual)
         if residual is None:
             return self.rms_forward(x)
         return self.add_rms_forward(x, residual)

@@ -13,11 +13,14 @@ from torch import nn
 
 from ..layers.activation import SiluAndMul
 from ..layers.attention import Attention
+from .. import ops
 from ..layers.embed_head import ParallelLMHead, VocabParallelEmbedding
 from ..layers.layernorm import RMSNorm
+from ..layers.fused import use_fused
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.rotary_embedding import get_rope
 from ..layers.tp import divide, tp_size
+from ..utils.context import get_context
 
 
 class Qwen3Attention(nn.Module):
@@ -44,6 +47,16 @@ class Qwen3Attention(nn.Module):
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        if use_fused(qkv):
+            # q/k RMSNorm + RoPE in place on the qkv activation and the K/V cache scatter: one launch
+            attn = self.attn
+            ops.qk_norm_rope_store(q.view(-1, self.num_heads, self.head_dim),
+                                   k.view(-1, self.num_kv_heads, self.head_dim),
+                                   v.view(-1, self.num_kv_heads, self.head_dim), positions,
+                                   self.q_norm.weight, self.k_norm.weight, self.q_norm.eps,
+                                   self.rotary_emb.cos_sin_cache, attn.k_cache, attn.v_cache,
+                                   get_context().slot_mapping)
+            return self.o_proj(attn(q, k, v, kv_stored=True))
         q = self.q_norm(q.view(-1, self.num_heads, self.head_dim)).view(q.shape)
         k = self.k_norm(k.view(-1, self.num_kv_heads, self.head_dim)).view(k.shape)
         q, k = self.rotary_emb(positions, q, k)

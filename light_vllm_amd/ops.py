@@ -190,3 +190,100 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     _lib.check(rc, "lv_decode_attn")
     del keep
     return out
+
+
+def qk_norm_rope_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, positions: torch.Tensor,
+                       q_weight: torch.Tensor, k_weight: torch.Tensor, eps: float,
+                       cos_sin_cache: torch.Tensor, k_cache: Optional[torch.Tensor] = None,
+                       v_cache: Optional[torch.Tensor] = None,
+                       slot_mapping: Optional[torch.Tensor] = None) -> None:
+    """Per-head RMSNorm of q and k, neox RoPE of both (in place), then the K/V cache scatter.
+
+    q: [N, Hq, 128], k/v: [N, Hkv, 128] bf16 views (row stride free, normally slices of the fused
+    qkv activation). positions int64 [N]. q_weight/k_weight bf16 [128]. cos_sin_cache fp32
+    [max_position, 128] (cos | sin). With k_cache/v_cache/slot_mapping None (or empty caches) the
+    store is skipped, as the reference does during warmup (lightvllm/layers/attention.py:149).
+    """
+    dev = _require_gpu(q, k, v, positions, q_weight, k_weight, cos_sin_cache)
+    N, Hq, D = q.shape
+    Hkv = k.size(1)
+    assert k.shape == (N, Hkv, D) and v.shape == (N, Hkv, D)
+    assert q.dtype == _BF16 and k.dtype == _BF16 and v.dtype == _BF16
+    assert q_weight.dtype == _BF16 and k_weight.dtype == _BF16
+    assert q_weight.numel() == D and k_weight.numel() == D and q_weight.is_contiguous() and k_weight.is_contiguous()
+    for t in (q, k, v):
+        assert t.stride(-1) == 1 and t.stride(1) == D
+    assert positions.dtype == torch.int64 and positions.is_contiguous() and positions.numel() == N
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous()
+    assert cos_sin_cache.dim() == 2 and cos_sin_cache.size(1) == D
+    store = k_cache is not None and v_cache is not None and k_cache.numel() > 0 and v_cache.numel() > 0
+    kc_ptr = vc_ptr = sm_ptr = None
+    num_slots = 0
+    if store:
+        _require_gpu(q, k_cache, v_cache, slot_mapping)
+        assert k_cache.dtype == _BF16 and v_cache.dtype == _BF16
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape
+        assert k_cache.numel() % (Hkv * D) == 0
+        assert slot_mapping.dtype == torch.int32 and slot_mapping.is_contiguous() and slot_mapping.numel() == N
+        kc_ptr, vc_ptr, sm_ptr = k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr()
+        num_slots = k_cache.numel() // (Hkv * D)
+    if N == 0:
+        return
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.lv_qk_norm_rope_store(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0),
+                                       v.stride(0), positions.data_ptr(), q_weight.data_ptr(),
+                                       k_weight.data_ptr(), float(eps), cos_sin_cache.data_ptr(),
+                                       cos_sin_cache.size(0), kc_ptr, vc_ptr, sm_ptr, num_slots, N,
+                                       Hq, Hkv, D, _stream_ptr(dev))
+    _lib.check(rc, "lv_qk_norm_rope_store")
+
+
+def add_rms_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                 eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMSNorm of x (+ residual). With a residual, `residual` is updated in place to the rounded
+    sum x + residual and the normalised sum is returned. x/residual: [N, hidden] bf16."""
+    dev = _require_gpu(x, weight) if residual is None else _require_gpu(x, residual, weight)
+    hidden = x.size(-1)
+    x2 = x.view(-1, hidden)
+    assert x2.dtype == _BF16 and weight.dtype == _BF16 and x2.stride(-1) == 1
+    assert weight.numel() == hidden and weight.is_contiguous()
+    N = x2.size(0)
+    res_ptr, res_stride = None, 0
+    if residual is not None:
+        r2 = residual.view(-1, hidden)
+        assert r2.shape == x2.shape and r2.dtype == _BF16 and r2.stride(-1) == 1
+        res_ptr, res_stride = r2.data_ptr(), r2.stride(0)
+    if out is None:
+        out = torch.empty((N, hidden), dtype=_BF16, device=dev)
+    o2 = out.view(-1, hidden)
+    assert o2.shape == x2.shape and o2.dtype == _BF16 and o2.stride(-1) == 1
+    if N:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.lv_add_rms_norm(x2.data_ptr(), res_ptr, weight.data_ptr(), o2.data_ptr(),
+                                     x2.stride(0), res_stride, o2.stride(0), N, hidden, float(eps),
+                                     _stream_ptr(dev))
+        _lib.check(rc, "lv_add_rms_norm")
+    return out.view(x.shape)
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu(x[..., :I]) * x[..., I:] for x [N, 2I] bf16 -> [N, I]."""
+    dev = _require_gpu(x)
+    inter = x.size(-1) // 2
+    assert x.size(-1) == 2 * inter
+    x2 = x.view(-1, 2 * inter)
+    assert x2.dtype == _BF16 and x2.stride(-1) == 1
+    N = x2.size(0)
+    if out is None:
+        out = torch.empty((*x.shape[:-1], inter), dtype=_BF16, device=dev)
+    o2 = out.view(-1, inter)
+    assert o2.size(0) == N and o2.dtype == _BF16 and o2.stride(-1) == 1
+    if N:
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.lv_silu_and_mul(x2.data_ptr(), o2.data_ptr(), x2.stride(0), o2.stride(0), N, inter,
+                                     _stream_ptr(dev))
+        _lib.check(rc, "lv_silu_and_mul")
+    return out

@@ -16,6 +16,7 @@ def declared_functions():
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
+        "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn"])
 
 

@@ -28,11 +28,19 @@ def _parts(golden, enforce_eager):
     return cfg, runner, Scheduler(cfg)
 
 
-@pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
-def test_config1_teacher_forced_parity(gpu, enforce_eager):
+@pytest.mark.parametrize("enforce_eager,fused", [(True, True), (False, True), (True, False)],
+                         ids=["eager", "hipgraph", "eager-unfused"])
+def test_config1_teacher_forced_parity(gpu, enforce_eager, fused):
+    """fused=False routes q/k RMSNorm, RoPE, add+RMSNorm and SwiGLU through the op-by-op torch
+    modules instead of the one-launch HIP kernels; both must meet the same bar."""
+    from light_vllm_amd.layers import fused as fused_switch
     golden = load_golden("e2e_config1.json")
-    cfg, runner, sch = _parts(golden, enforce_eager)
-    compared, soft, hard, max_dev = replay(golden, runner, sch, tie_ulps=TIE_ULPS)
+    old = fused_switch.set_enabled(fused)
+    try:
+        cfg, runner, sch = _parts(golden, enforce_eager)
+        compared, soft, hard, max_dev = replay(golden, runner, sch, tie_ulps=TIE_ULPS)
+    finally:
+        fused_switch.set_enabled(old)
     print(f"compared {compared} tokens, max top-5 logit deviation {max_dev:.4f}, tie flips {soft}, hard mismatches {hard}")
     runner.exit()
     assert compared == 4 * golden["max_tokens"]

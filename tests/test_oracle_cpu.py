@@ -94,3 +94,56 @@ def test_dispatcher_decode_reads_the_token_it_just_stored():
     assert torch.equal(kc[blk, 0].view(-1), k_new.view(-1))
     manual = decode_ref(case["q"], kc, vc, case["context_lens"], case["block_table"], case["scale"])
     assert torch.equal(out.view(1, Hq, D), manual)
+
+
+# ---------------------------------------------------------------------------------------------
+# layer-step oracle (RMSNorm, add+RMSNorm, RoPE) against outputs of the reference's own modules
+# ---------------------------------------------------------------------------------------------
+def _layers_golden():
+    import os
+    from safetensors import safe_open
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "layers_small.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+        return {k: f.get_tensor(k) for k in f.keys()}, meta
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16)
+
+
+def test_layers_oracle_matches_reference_modules_bitwise():
+    from oracle import layers_oracle as lo
+    g, meta = _layers_golden()
+    eps = float(meta["eps"])
+    table = lo.cos_sin_table(128, int(meta["max_position"]), float(meta["base"]))
+    assert torch.equal(table[g["positions"]], g["cos_sin_rows"])
+    assert torch.equal(_bits(lo.rms_norm_ref(g["q"], g["q_weight"], eps)), _bits(g["q_normed"]))
+    assert torch.equal(_bits(lo.rms_norm_ref(g["k"], g["k_weight"], eps)), _bits(g["k_normed"]))
+    q_rot, k_rot = lo.qk_norm_rope_ref(g["q"], g["k"], g["positions"], g["q_weight"], g["k_weight"], eps, table)
+    assert torch.equal(_bits(q_rot), _bits(g["q_rot"]))
+    assert torch.equal(_bits(k_rot), _bits(g["k_rot"]))
+    assert torch.equal(_bits(lo.rms_norm_ref(g["x"], g["weight"], eps)), _bits(g["rms_out"]))
+    out, res = lo.add_rms_norm_ref(g["x"], g["residual"], g["weight"], eps)
+    assert torch.equal(_bits(out), _bits(g["add_out"]))
+    assert torch.equal(_bits(res), _bits(g["add_res"]))
+
+
+def test_package_layer_modules_match_the_layers_oracle():
+    """The torch modules the CPU plumbing path uses are the same arithmetic as the oracle."""
+    from light_vllm_amd.layers.layernorm import RMSNorm
+    from light_vllm_amd.layers.rotary_embedding import RotaryEmbedding
+    from oracle import layers_oracle as lo
+    g, meta = _layers_golden()
+    eps = float(meta["eps"])
+    norm = RMSNorm(1024, eps)
+    norm.weight.data = g["weight"].clone()
+    out, res = norm(g["x"].clone(), g["residual"].clone())
+    assert torch.equal(_bits(out), _bits(g["add_out"])) and torch.equal(_bits(res), _bits(g["add_res"]))
+    rope = RotaryEmbedding(128, 128, int(meta["max_position"]), float(meta["base"]))
+    N = g["q"].size(0)
+    q_rot, k_rot = rope(g["positions"], g["q_normed"].view(N, -1), g["k_normed"].view(N, -1))
+    assert torch.equal(_bits(q_rot.view_as(g["q_rot"])), _bits(g["q_rot"]))
+    assert torch.equal(_bits(k_rot.view_as(g["k_rot"])), _bits(g["k_rot"]))
+    x = g["x"][:, :512]
+    assert torch.equal(_bits(lo.silu_and_mul_ref(x)), _bits(torch.nn.functional.silu(x[:, :256]) * x[:, 256:]))
