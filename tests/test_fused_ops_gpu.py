@@ -1,8 +1,13 @@
 """HIP kernels for the memory-bound steps around attention (lv_qk_norm_rope_store, lv_add_rms_norm,
 lv_silu_and_mul) against the CPU layer oracle and the committed outputs of the reference's own
-modules. Bar: cache rows bit-identical to the q/k/v rows they are copies of; normalised values
-within ONE bf16 rounding step of the oracle (the mean of squares is summed in a different order
-and rsqrt is the device's), at least 99 % of elements bit-identical."""
+modules. Bar: cache rows bit-identical to the q/k/v rows they are copies of; at least 99 % of all
+computed elements bit-identical to the oracle; the rest within TWO bf16 rounding steps. (The mean
+of squares is summed in a different order and rsqrt is the device's, so x * rsqrt(...) can land on
+the other side of a rounding boundary: one step, which the following multiplication by the weight
+can stretch to two when it crosses into a binade with half the relative spacing.) After the
+rotation such a difference in a normalised value n shows up as at most step(n) * (|cos| + |sin|) in
+either output of its pair, which can be many steps of an output that cancelled to something small,
+so rotated values are held to 3 steps of the larger member of their input pair instead."""
 import pytest
 import torch
 
@@ -25,8 +30,19 @@ def _ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 def _close(got, want, what):
     d = _ulp_diff(got, want)
-    assert int(d.max()) <= 1, f"{what}: {int(d.max())} bf16 steps off"
+    assert int(d.max()) <= 2, f"{what}: {int(d.max())} bf16 steps off"
     frac = float((d == 0).float().mean())
+    assert frac >= 0.99, f"{what}: only {frac:.4f} of elements bit-identical"
+
+
+def _close_rotated(got, want, normed, what):
+    """normed: the oracle's values before the rotation, [N, H, 128]."""
+    mag = normed.float().abs()
+    pair = torch.maximum(mag[..., :64], mag[..., 64:])
+    tol = 3 * 2.0 ** -7 * torch.cat((pair, pair), dim=-1) + 1e-30
+    diff = (got.float().cpu() - want.float()).abs()
+    assert bool((diff <= tol).all()), f"{what}: off by {float((diff / tol).max()):.2f} x tolerance"
+    frac = float((_ulp_diff(got, want) == 0).float().mean())
     assert frac >= 0.99, f"{what}: only {frac:.4f} of elements bit-identical"
 
 
@@ -43,8 +59,8 @@ def test_golden_from_reference_modules(gpu):
     v = torch.zeros_like(k)
     ops.qk_norm_rope_store(q, k, v, g["positions"].to(gpu), g["q_weight"].to(gpu), g["k_weight"].to(gpu),
                            eps, table)
-    _close(q, g["q_rot"], "q")
-    _close(k, g["k_rot"], "k")
+    _close_rotated(q, g["q_rot"], g["q_normed"], "q")
+    _close_rotated(k, g["k_rot"], g["k_normed"], "k")
     out = ops.add_rms_norm(g["x"].to(gpu), None, g["weight"].to(gpu), eps)
     _close(out, g["rms_out"], "rms")
     res = g["residual"].to(gpu)
@@ -83,8 +99,8 @@ def test_qk_norm_rope_store(gpu, N, Hq, Hkv):
     ops.qk_norm_rope_store(dq.view(N, Hq, D), dk.view(N, Hkv, D), dv.view(N, Hkv, D), positions.to(gpu),
                            wq.to(gpu), wk.to(gpu), EPS, table.to(gpu), kc, vc, slots.to(gpu))
     torch.cuda.synchronize()
-    _close(dq.reshape(N, Hq, D), q_want, "q")
-    _close(dk.reshape(N, Hkv, D), k_want, "k")
+    _close_rotated(dq.reshape(N, Hq, D), q_want, lo.rms_norm_ref(q_ref.reshape(N, Hq, D), wq, EPS), "q")
+    _close_rotated(dk.reshape(N, Hkv, D), k_want, lo.rms_norm_ref(k_ref.reshape(N, Hkv, D), wk, EPS), "k")
     assert _bits_equal(dv, v_ref)                            # v is read-only
     # cache rows: exact copies of what the kernel left in k / found in v; other rows untouched
     kc_want, vc_want = kc0.clone().view(-1, Hkv * D), vc0.clone().view(-1, Hkv * D)
@@ -107,8 +123,8 @@ def test_qk_norm_rope_without_store_and_position_clamp(gpu):
     dq, dk = q.to(gpu), k.to(gpu)
     ops.qk_norm_rope_store(dq, dk, v.to(gpu), positions.to(gpu), w.to(gpu), w.to(gpu), EPS, table.to(gpu),
                            torch.tensor([]), torch.tensor([]), None)     # unallocated caches: no store
-    _close(dq, q_want, "q")
-    _close(dk, k_want, "k")
+    _close_rotated(dq, q_want, lo.rms_norm_ref(q, w, EPS), "q")
+    _close_rotated(dk, k_want, lo.rms_norm_ref(k, w, EPS), "k")
 
 
 @pytest.mark.parametrize("N,hidden", [(1, 1024), (256, 4096), (33, 5120), (5, 8192), (1000, 1024), (3, 136)])
