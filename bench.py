@@ -13,6 +13,13 @@ stay fixed ("weak" scaling: TP used to serve a proportionally larger batch).
 `value` = algorithmic bytes of all launches of a step, summed over ranks, / max-over-ranks step time.
 Inputs are resident in HBM before the timed region.
 
+After the timed region two auxiliary measurements are attached to the same JSON line (they never
+touch `value`): `collectives` times the RCCL sum all-reduce at the two message sizes the tensor-parallel
+model issues (decode: [256, 4096] bf16 = 2 MiB, prefill: [16384, 4096] bf16 = 128 MiB), and `e2e`
+is the engine's own decode / prefill tok/s (tools/e2e_bench.py: Qwen3-8B shapes, random weights,
+TP = N, one process per GPU) run in a child process with its own time limit, so a failure there
+is reported as text and cannot take the headline number with it. `--no-aux` skips both.
+
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
 from __future__ import annotations
@@ -20,6 +27,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
 import time
 
@@ -68,12 +77,67 @@ def cpu_baseline(case_cpu, Hq, Hkv, budget_s=12.0):
                       f"{reps} calls, {per_call * 1e3:.1f} ms/call"}
 
 
+def allreduce_bench(dist, dev, n, iters=20):
+    """Average time of an in-place bf16 sum all-reduce (the collective RowParallelLinear and the
+    vocab-parallel embedding issue) at decode- and prefill-sized messages; busbw = 2(n-1)/n * S / t."""
+    out = {}
+    for name, rows in (("decode_2MiB", 256), ("prefill_128MiB", 16384)):
+        x = torch.ones(rows, 4096, dtype=torch.bfloat16, device=dev)
+        for _ in range(3):
+            dist.all_reduce(x)
+            x.fill_(1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(x)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[name] = {"avg_us": round(us, 1),
+                     "busbw_GBs": round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)}
+        del x
+    return out
+
+
+def e2e_leg(n, port, mode, limit_s):
+    """tools/e2e_bench.py in a child process group of its own (killed as a group at the limit)."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--model", "8b", "--tp", str(n),
+           "--batch", "256", "--prompt-len", "1024", "--new-tokens", "33", "--modes", mode,
+           "--dist-port", str(port)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                        "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        return {"mode": mode, "error": f"no result within {limit_s} s"}
+    for line in out.splitlines():
+        if line.startswith("{"):
+            try:
+                rec = json.loads(line)
+                rec["wall_s"] = round(time.perf_counter() - t0, 1)
+                return rec
+            except ValueError:
+                pass
+    return {"mode": mode, "error": f"exit code {proc.returncode}: {err.strip()[-300:]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the collectives and e2e legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,10 +258,29 @@ def main():
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         case_cpu = (q.cpu(), kv[0, 0].cpu(), kv[1, 0].cpu(), ctx_cpu, bt_cpu, scale)
         result["cpu_baseline"] = cpu_baseline(case_cpu, Hq, Hkv)
+    t_aux = time.perf_counter()
+    if n > 1 and not args.no_aux:
+        try:
+            result["collectives"] = allreduce_bench(dist, dev, n)
+        except Exception as exc:   # reported, never fatal for the headline number
+            result["collectives"] = {"error": repr(exc)[:300]}
+    del kv, q, k_new, qkv, v_new, out
+    torch.cuda.empty_cache()
+    if n > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not args.no_aux:
+        # every bench rank has released its GPU memory; the engine starts its own one process per GPU
+        port = int(os.environ.get("MASTER_PORT", "29500")) + 17
+        legs = [e2e_leg(n, port, "eager", 170)]
+        if "error" not in legs[0]:
+            legs.append(e2e_leg(n, port + 1, "graph", 170))
+        result["e2e"] = {"what": "tools/e2e_bench.py: engine generate(), Qwen3-8B shapes, random weights, "
+                                 f"TP={n}, batch 256 x 1024-token prompts, 33 new tokens, greedy",
+                         "runs": legs}
+        result["aux_seconds"] = round(time.perf_counter() - t_aux, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if n > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

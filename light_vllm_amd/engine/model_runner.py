@@ -86,7 +86,13 @@ class ModelRunner:
 
         if self.world_size > 1:
             if rank == 0:
-                self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
+                try:
+                    self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
+                except FileExistsError:     # left behind by a run that died: replace it
+                    stale = SharedMemory(name=_SHM_NAME)
+                    stale.close()
+                    stale.unlink()
+                    self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
                 dist.barrier()
             else:
                 dist.barrier()

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--modes", default="eager,graph")
     ap.add_argument("--blocks", type=int, default=0, help="cap on KV blocks (0 = size from free HBM)")
     ap.add_argument("--max-model-len", type=int, default=4096)
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel size: one process per GPU, RCCL over xGMI")
+    ap.add_argument("--dist-port", type=int, default=2333, help="TCP port of the TP group's rendezvous")
     args = ap.parse_args()
 
     from light_vllm_amd.llm import LLM
@@ -56,7 +58,8 @@ def main():
         llm = LLM(None, hf_config=hf_config(args.model), enforce_eager=(mode == "eager"),
                   max_num_seqs=max(args.batch, 1), num_kvcache_blocks=args.blocks or max(need_blocks, 64),
                   max_model_len=args.max_model_len, max_num_batched_tokens=max(16384, args.max_model_len),
-                  random_seed=0, random_on_device=True)
+                  random_seed=0, random_on_device=True, tensor_parallel_size=args.tp,
+                  dist_init_method=f"tcp://127.0.0.1:{args.dist_port}")
         t_init = time.time() - t0
         outs = llm.generate(prompts, sp)
         st = dict(llm.last_stats)
@@ -64,7 +67,7 @@ def main():
         llm.exit()
         del llm
         torch.cuda.empty_cache()
-        print(json.dumps({"model": f"Qwen3-{args.model} shapes (random init)", "mode": mode, "tp": 1,
+        print(json.dumps({"model": f"Qwen3-{args.model} shapes (random init)", "mode": mode, "tp": args.tp,
                           "batch": args.batch, "prompt_len": args.prompt_len, "new_tokens": args.new_tokens,
                           "decode_tok_s": round(st["avg_decode_tok_s"], 1),
                           "prefill_tok_s": round(st["avg_prefill_tok_s"], 1),
