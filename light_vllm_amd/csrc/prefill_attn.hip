@@ -72,23 +72,101 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
 #define LV_CLOCK_END
 #endif
 
-template <int V>
-struct IntC { static constexpr int value = V; };
-
 // Rescale of the running output is skipped while no row's maximum grows by more than this many
 // powers of two; P then reaches at most 2^kDeferLog2 instead of 1, which fp32 sums and the bf16
 // P operand (same relative precision at any magnitude) absorb.
 constexpr float kDeferLog2 = 6.0f;
 
-// NW = waves per workgroup, RB = 32-row query blocks per wave (1); the workgroup's query tile is
-// 32*RB*NW rows. Only RB = 1 is instantiated: with RB = 2 (each K/V fragment feeding two MFMAs,
-// one wave per SIMD) hipcc parks values in AGPRs and pays v_accvgpr_read/write copies around every
-// MFMA, which measured 30 % slower than RB = 1 at two waves per SIMD.
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+// max of x over the lane pair (l, l ^ 32), on the vector ALU (v_permlane32_swap, no LDS round trip).
+// The two result words are copied to scalars before the bit cast: __builtin_bit_cast applied
+// directly to a vector element (sw[1], w.y) compiles to element 0 with this hipcc.
+__device__ __forceinline__ float pair32_max(float x) {
+  const unsigned xb = __builtin_bit_cast(unsigned, x);
+  const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+  const unsigned lo = sw[0], hi = sw[1];
+  return fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+}
+
+// ---- RB = 2 structure: registers owned by inline asm.
+// At one wave per SIMD the wave has the whole 512-entry register file, but hipcc, left to place an
+// accumulator that both MFMAs and vector code (the rare rescale) touch, moves it between the two
+// halves of the file around every tile. So the output accumulator and the Q fragments are kept in
+// accumulator registers that only asm statements name, and hipcc never sees them as values:
+//   a[0:63]    O^T of row block 0 (column block dt at a[16 dt : 16 dt + 15])
+//   a[64:127]  O^T of row block 1
+//   a[128:159] Q^T fragments of row block 0 (d-step s at a[128 + 4 s : +3]);  a[160:191] row block 1
+// hipcc's own values must all fit the 256 vector registers (it would use free accumulator
+// registers as spill space): after every edit check the .s for v_accvgpr_* outside ASMSTART/ASMEND.
+// hipcc does not know these statements are MFMAs, so the wait states between an MFMA result and a
+// vector instruction reading it, and between a vector write and an MFMA reading it, are placed by
+// hand (s_nop inside or beside the statements).
+#define LV_ACC_CLOBBERS_0_63 \
+  "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15", \
+  "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31", \
+  "a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47", \
+  "a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
+#define LV_ACC_CLOBBERS_64_127 \
+  "a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79", \
+  "a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95", \
+  "a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111", \
+  "a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+#define LV_ACC_CLOBBERS_128_191 \
+  "a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143", \
+  "a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159", \
+  "a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175", \
+  "a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IntC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// scores (vector registers) = K fragment (vector) x Q^T fragment (accumulator registers QB..QB+3)
+template <int QB, bool ZERO_C>
+__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& k) {
+  if constexpr (ZERO_C)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], 0" : "=&v"(d) : "v"(k), "n"(QB), "n"(QB + 3));
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(d) : "v"(k), "n"(QB), "n"(QB + 3));
+}
+// O^T (accumulator registers OB..OB+15) += V^T fragment x P^T fragment (both vector registers)
+template <int OB>
+__device__ __forceinline__ void mfma_o(const bf16x8& v, const bf16x8& pf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(v), "v"(pf), "n"(OB), "n"(OB + 15));
+}
+template <int R>
+__device__ __forceinline__ void acc_write(float x) {
+  asm volatile("v_accvgpr_write_b32 a[%1:%1], %0" ::"v"(x), "n"(R));
+}
+template <int R>
+__device__ __forceinline__ float acc_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1:%1]" : "=v"(x) : "n"(R));
+  return x;
+}
+// a[R] *= alpha (vector register), through a scratch vector register
+template <int R>
+__device__ __forceinline__ void acc_scale(float alpha) {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a[%2:%2]\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a[%2:%2], %0"
+               : "=&v"(t) : "v"(alpha), "n"(R));
+}
+
+// NW = waves per workgroup, RB = 32-row query blocks per wave; the workgroup's query tile is
+// 32*RB*NW rows. RB = 1 runs two waves per SIMD on compiler-allocated registers. RB = 2 (NW = 4)
+// runs one wave per SIMD on the whole 512-register file: every K and V fragment read from LDS
+// feeds two MFMAs, which halves the LDS traffic per FLOP.
 // DMA = true stages K/V tiles HBM -> LDS directly (global_load_lds, no VGPRs, no ds_write).
 template <bool PAGED, int NW, int RB, bool DMA>
 __global__ __launch_bounds__(64 * NW, (RB == 2 ? 1 : 2))
 void prefill_attn_kernel(const PrefillParams p) {
-  static_assert(RB == 1, "one 32-row block per wave");
+  static_assert(RB == 1 || (RB == 2 && NW == 4), "RB = 2 is the 4-wave, one-wave-per-SIMD structure");
   constexpr int BM = 32 * RB * NW;  // query rows per workgroup
   constexpr int NST = 16 / NW;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 4 * NW;     // tile rows between two chunks of one thread
@@ -143,6 +221,25 @@ void prefill_attn_kernel(const PrefillParams p) {
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(qf[rb][s]));
+
+  if constexpr (RB == 2) {
+    // claim a[0:191] for the asm statements (this also sizes the kernel's accumulator file), then
+    // park the Q^T fragments in a[128:191] and zero the output accumulator a[0:127]
+    asm volatile("" ::: LV_ACC_CLOBBERS_0_63, LV_ACC_CLOBBERS_64_127, LV_ACC_CLOBBERS_128_191);
+    static_for<0, 2>([&](auto rb_c) {
+      static_for<0, 8>([&](auto s_c) {
+        constexpr int RBI = decltype(rb_c)::value, S = decltype(s_c)::value;
+        const u32x4 w = __builtin_bit_cast(u32x4, qf[RBI][S]);
+        const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];   // scalars first: see pair32_max
+        acc_write<128 + 32 * RBI + 4 * S + 0>(__builtin_bit_cast(float, w0));
+        acc_write<128 + 32 * RBI + 4 * S + 1>(__builtin_bit_cast(float, w1));
+        acc_write<128 + 32 * RBI + 4 * S + 2>(__builtin_bit_cast(float, w2));
+        acc_write<128 + 32 * RBI + 4 * S + 3>(__builtin_bit_cast(float, w3));
+      });
+    });
+    static_for<0, 128>([&](auto r_c) { acc_write<decltype(r_c)::value>(0.f); });
+    asm volatile("s_nop 3");   // accumulator writes -> first MFMA reading them
+  }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
@@ -318,10 +415,7 @@ void prefill_attn_kernel(const PrefillParams p) {
     float mx = sacc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-    // exchange with lane ^ 32 on the VALU (v_permlane32_swap): no LDS round trip
-    const unsigned mb = __builtin_bit_cast(unsigned, mx);
-    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-    return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    return pair32_max(mx);
   };
   // Running-max update. The accumulator is rescaled only when some row of the wave outgrows its
   // running maximum by more than the deferral threshold (always on a row's first visible keys,
@@ -438,6 +532,157 @@ void prefill_attn_kernel(const PrefillParams p) {
     LV_STAMP(6)
   };
 
+  // ---- RB = 2: one 64-key tile for the wave's two 32-row blocks, in four phases of 16 MFMAs.
+  //   P1  S0 = K[0:32] Q^T            (both row blocks; each K fragment feeds two MFMAs)
+  //       row maxima of S0, running-max update (accumulator rescale applied here: every earlier
+  //       P V is complete)
+  //   P2  S1 = K[32:64] Q^T     with  P0 = exp2(S0) issued between the MFMAs, one pair per MFMA
+  //       row maxima of S1; a rescale it asks for is held back until P0 V has been added
+  //   P3  O += V[0:32]^T P0     with  P1 = exp2(S1) between the MFMAs
+  //   P4  O += V[32:64]^T P1
+  // The order inside P2/P3 is the source order: a scheduling barrier closes every MFMA + filler
+  // group, because hipcc cannot see an MFMA in the asm statement and would not interleave by itself.
+  auto mfma_settle = [&](f32x16& a, f32x16& b) {
+    // 16 wait states between the last MFMA writing these registers and a vector read of them
+    asm volatile("s_nop 15" : "+v"(a), "+v"(b));
+  };
+  auto row_max2 = [&](int ks0, int rb, f32x16& sacc) -> float {
+    if (ks0 + 31 > wrow0 + 32 * rb + coff) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = ks0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (key > my_lim[rb]) sacc[r] = -INFINITY;
+      }
+    }
+    float a[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a[j]) : "v"(sacc[3 * j]), "v"(sacc[3 * j + 1]), "v"(sacc[3 * j + 2]));
+    float b0, b1;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(a[3]), "v"(a[4]), "v"(sacc[15]));
+    const float mx = fmaxf(b0, b1);
+    return pair32_max(mx);
+  };
+  // O and l of one row block times alpha; the accumulator's last MFMA must have retired
+  auto rescale2 = [&](auto rb_c, float alpha) {
+    constexpr int RBI = decltype(rb_c)::value;
+    l_run[RBI] *= alpha;
+    asm volatile("s_nop 15");
+    static_for<0, 64>([&](auto r_c) { acc_scale<64 * RBI + decltype(r_c)::value>(alpha); });
+    asm volatile("s_nop 3");
+  };
+  auto new_max2 = [&](int rb, float mx) -> float {
+    const float m_new = fmaxf(m_run[rb], mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run[rb] - m_use) * cexp);
+    m_run[rb] = m_new;
+    return alpha;
+  };
+  // two probabilities of one row block: registers R, R+1 of its score tile
+  auto exp_pair = [&](const f32x16& sacc, bf16x8 (&pf)[2], float& ps_a, float& ps_b, float mc, auto r_c) {
+    constexpr int R = decltype(r_c)::value;
+    const float pe0 = __builtin_amdgcn_exp2f(fmaf(sacc[R], cexp, -mc));
+    const float pe1 = __builtin_amdgcn_exp2f(fmaf(sacc[R + 1], cexp, -mc));
+    ps_a += pe0;
+    ps_b += pe1;
+    pf[R >> 3][R & 7] = static_cast<__bf16>(pe0);
+    pf[R >> 3][(R & 7) + 1] = static_cast<__bf16>(pe1);
+  };
+
+  auto compute2 = [&](int tile, auto buf_c) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr int kBufOff = BUF * 2 * kTileBytes;
+    const int kt0 = tile * BN;
+    if (kt0 > wrow0 + 63 + coff) return;   // every row of the wave lies above this tile
+
+    bf16x8 kx[8];
+    bf16x8 va[2][4], vb[2][4];
+    f32x16 s0[2], s1[2];          // [row block] scores of keys 0-31 / 32-63
+    bf16x8 p0[2][2], p1[2][2];    // [row block][16-key step]
+
+    // ---- P1
+    load_ka(kx, kBufOff);
+    static_for<0, 8>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value;
+      mfma_s<128 + 4 * S, S == 0>(s0[0], kx[S]);
+      mfma_s<160 + 4 * S, S == 0>(s0[1], kx[S]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    load_ka(kx, kBufOff + 8192);
+    load_va(va, kBufOff);
+    mfma_settle(s0[0], s0[1]);
+    float mc0[2];
+    static_for<0, 2>([&](auto rb_c) {
+      constexpr int RBI = decltype(rb_c)::value;
+      const float mx = row_max2(kt0, RBI, s0[RBI]);
+      if (__builtin_amdgcn_ballot_w64(mx - m_run[RBI] > defer_raw) != 0) rescale2(rb_c, new_max2(RBI, mx));
+      mc0[RBI] = ((m_run[RBI] == -INFINITY) ? 0.f : m_run[RBI]) * cexp;
+    });
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- P2: S1 with P0 = exp2(S0)
+    float psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
+    static_for<0, 8>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value;
+      mfma_s<128 + 4 * S, S == 0>(s1[0], kx[S]);
+      exp_pair(s0[0], p0[0], psa[0], psb[0], mc0[0], IntC<2 * S>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_s<160 + 4 * S, S == 0>(s1[1], kx[S]);
+      exp_pair(s0[1], p0[1], psa[1], psb[1], mc0[1], IntC<2 * S>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    l_run[0] += psa[0] + psb[0];
+    l_run[1] += psa[1] + psb[1];
+    load_va(vb, kBufOff + 8192);
+    mfma_settle(s1[0], s1[1]);
+    float mc1[2], alpha1[2];
+    bool resc1[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float mx = row_max2(kt0 + 32, rb, s1[rb]);
+      resc1[rb] = __builtin_amdgcn_ballot_w64(mx - m_run[rb] > defer_raw) != 0;
+      alpha1[rb] = 1.f;
+      if (resc1[rb]) alpha1[rb] = new_max2(rb, mx);
+      mc1[rb] = ((m_run[rb] == -INFINITY) ? 0.f : m_run[rb]) * cexp;
+    }
+    // P0 was written by vector instructions: wait states before an MFMA reads it
+    asm volatile("s_nop 1" : "+v"(p0[0][0]), "+v"(p0[0][1]), "+v"(p0[1][0]), "+v"(p0[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- P3: O += V[0:32]^T P0 with P1 = exp2(S1)
+    psa[0] = psa[1] = psb[0] = psb[1] = 0.f;
+    static_for<0, 8>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;   // 16-key step I >> 2, column block I & 3
+      constexpr int KS = I >> 2, DT = I & 3;
+      mfma_o<16 * DT>(va[KS][DT], p0[0][KS]);
+      exp_pair(s1[0], p1[0], psa[0], psb[0], mc1[0], IntC<2 * I>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_o<64 + 16 * DT>(va[KS][DT], p0[1][KS]);
+      exp_pair(s1[1], p1[1], psa[1], psb[1], mc1[1], IntC<2 * I>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // P0 V (formed at the old scale) is in; bring O and l to the new one where S1 asked for it
+    if (resc1[0]) rescale2(IntC<0>{}, alpha1[0]);
+    if (resc1[1]) rescale2(IntC<1>{}, alpha1[1]);
+    l_run[0] += psa[0] + psb[0];
+    l_run[1] += psa[1] + psb[1];
+    asm volatile("s_nop 1" : "+v"(p1[0][0]), "+v"(p1[0][1]), "+v"(p1[1][0]), "+v"(p1[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- P4: O += V[32:64]^T P1
+    static_for<0, 8>([&](auto i_c) {
+      constexpr int I = decltype(i_c)::value;
+      constexpr int KS = I >> 2, DT = I & 3;
+      mfma_o<16 * DT>(vb[KS][DT], p1[0][KS]);
+      mfma_o<64 + 16 * DT>(vb[KS][DT], p1[1][KS]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run_tile = [&](int tile, auto buf_c) {
+    if constexpr (RB == 2) compute2(tile, buf_c); else compute(tile, buf_c);
+  };
+
   // ---- main loop, LDS-DMA staging: tile t+1 is copied into the other buffer while tile t is
   // computed; the barrier at the end of the interval (its fence waits for the copies) publishes it.
   if constexpr (DMA) {
@@ -448,14 +693,14 @@ void prefill_attn_kernel(const PrefillParams p) {
     for (int tile = 0; tile < ntiles; tile += 2) {
       if (tile + 1 < ntiles) stage_dma(tile + 1, IntC<1>{});
       LV_STAMP(3)
-      compute(tile, IntC<0>{});
+      run_tile(tile, IntC<0>{});
       LV_STAMP(1)
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
         if (tile + 2 < ntiles) stage_dma(tile + 2, IntC<0>{});
         LV_STAMP(3)
-        compute(tile + 1, IntC<1>{});
+        run_tile(tile + 1, IntC<1>{});
         LV_STAMP(1)
         if (!(LV_ABL & 256)) __syncthreads();
         LV_STAMP(0)
@@ -471,7 +716,7 @@ void prefill_attn_kernel(const PrefillParams p) {
       if (ntiles > 1) stage_load(1);
     }
     for (int tile = 0; tile < ntiles; tile += 2) {
-      compute(tile, IntC<0>{});
+      run_tile(tile, IntC<0>{});
       if (tile + 1 < ntiles) stage_write(IntC<1>{});
       LV_STAMP(1)
       // the next loads are issued before the barrier: a wave that gets here early spends its
@@ -481,7 +726,7 @@ void prefill_attn_kernel(const PrefillParams p) {
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
-        compute(tile + 1, IntC<1>{});
+        run_tile(tile + 1, IntC<1>{});
         if (tile + 2 < ntiles) stage_write(IntC<0>{});
         LV_STAMP(1)
         if (tile + 3 < ntiles) stage_load(tile + 3);
@@ -494,6 +739,17 @@ void prefill_attn_kernel(const PrefillParams p) {
   LV_STAMP_FLUSH
 
   // ---- epilogue: normalise and store this lane's rows (d = 32*dt + (r&3) + 8*(r>>2) + 4*h)
+  if constexpr (RB == 2) {
+    asm volatile("s_nop 15");   // last MFMA -> accumulator reads
+    static_for<0, 2>([&](auto rb_c) {
+      static_for<0, 4>([&](auto dt_c) {
+        static_for<0, 16>([&](auto r_c) {
+          constexpr int RBI = decltype(rb_c)::value, DT = decltype(dt_c)::value, R = decltype(r_c)::value;
+          oacc[RBI][DT][R] = acc_read<64 * RBI + 16 * DT + R>();
+        });
+      });
+    });
+  }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
@@ -736,9 +992,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     const float b3 = max3(a[9], sa[15], sb[15]);
     float mx = fmaxf(max3(b0, b1, b2), b3);
     if (LV_ABL & 1024) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
-    const unsigned mb = __builtin_bit_cast(unsigned, mx);
-    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-    mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    mx = pair32_max(mx);
     if (LV_ABL & 2048) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
     const bool fresh = m_run == -INFINITY;
     if (__builtin_amdgcn_ballot_w64(fresh || mx > kDeferLog2) != 0) {
@@ -965,14 +1219,17 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
     return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
-  // cfg 2: the phase-locked 8-wave kernel (long prompts).
+  // cfg 2: the phase-locked 8-wave kernel (long prompts);
+  // cfg 3: 4 waves x 64 rows, one wave per SIMD, asm-placed MFMAs (opt-in).
   // LV_PREFILL_CFG / LV_PREFILL_DMA override the choice (read on every call: tests switch them).
   const char* env_cfg = getenv("LV_PREFILL_CFG");
   const char* env_dma = getenv("LV_PREFILL_DMA");
   const int force = env_cfg ? atoi(env_cfg) : -1;
   const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q >= 1024 ? 1 : 0));
   const int dma = env_dma ? atoi(env_dma) : 0;
-  if (cfg == 2) {
+  if (cfg == 3) {
+    if (p.block_table) launch_cfg<true, 4, 2, false>(p, stream); else launch_cfg<false, 4, 2, false>(p, stream);
+  } else if (cfg == 2) {
     if (p.block_table) launch_pp<true>(p, stream); else launch_pp<false>(p, stream);
   } else if (p.block_table) {
     if (cfg == 1) { if (dma) launch_cfg<true, 8, 1, true>(p, stream); else launch_cfg<true, 8, 1, false>(p, stream); }
