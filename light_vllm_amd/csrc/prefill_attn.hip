@@ -1198,6 +1198,456 @@ void prefill_pp_kernel(const PrefillParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One wave per SIMD: 4 waves x 64 query rows (two 32-row blocks per wave), the whole 512-entry
+// register file per wave. Every K and V fragment read from LDS feeds two MFMAs (one per row block),
+// half the LDS traffic per FLOP of the 32-rows-per-wave kernels. O^T and the Q^T fragments live in
+// accumulator registers that only asm statements name (see mfma_s / mfma_o above); scores,
+// probabilities and K/V fragments are ordinary hipcc values in the 256 vector registers.
+//
+// Software pipeline over K/V tiles, one workgroup barrier per tile. Iteration i runs two phases of
+// 32 MFMAs, each MFMA followed by its share of the vector work (source order = issue order: a
+// scheduling barrier closes every group, and an empty asm pins the arithmetic, which would
+// otherwise sink to its first user):
+//   QK phase   S(i+1) = K(i+1) Q^T          beside   P(i) second half = exp2(S(i) keys 32-63)
+//   PV phase   O += V(i)^T P(i)             beside   row maxima of S(i+1), running-max decision,
+//                                                    P(i+1) first half = exp2(S(i+1) keys 0-31)
+// A rescale decided for tile i+1 during PV(i) scales l at once and O after PV(i) has been added
+// (P(i) was formed at the old scale). K/V tiles arrive by LDS-DMA (global_load_lds, 1 KiB per wave
+// instruction, swizzle applied to the per-lane source address), K two tiles ahead and V one, each
+// in a 2-slot ring; the DMA is inline asm with its own vmcnt(0) before the barrier, so hipcc
+// neither waits for it early nor orders LDS reads behind it.
+template <bool PAGED>
+__global__ __launch_bounds__(256, 1)
+void prefill_w64_kernel(const PrefillParams p) {
+  constexpr int NW = 4;
+  constexpr int BM = 64 * NW;
+  // K slot s at s * kTileBytes, V slot s at (2 + s) * kTileBytes
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTileBytes];
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  const int G = p.num_heads / p.num_kv_heads;
+  int wg = blockIdx.x;
+  const int kvh = wg % p.num_kv_heads;
+  wg /= p.num_kv_heads;
+  const int hq = kvh * G + wg % G;
+  wg /= G;
+  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
+  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
+  const int b = wg / qtiles;
+  const int q_start = p.cu_q[b];
+  const int Lq = p.cu_q[b + 1] - q_start;
+  const int k_start = p.cu_k[b];
+  const int Lk = p.cu_k[b + 1] - k_start;
+  if (q0 >= Lq) return;
+  const int coff = Lk - Lq;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int h = lane >> 5;
+  const int c = lane & 31;
+  const int wrow0 = q0 + wave * 64;
+  const int my_lim0 = wrow0 + c + coff;        // last visible key of this lane's row in block 0
+  const int my_lim1 = my_lim0 + 32;
+
+  // ---- Q^T fragments -> a[128:191]; O^T a[0:127] = 0
+  asm volatile("" ::: LV_ACC_CLOBBERS_0_63, LV_ACC_CLOBBERS_64_127, LV_ACC_CLOBBERS_128_191);
+  static_for<0, 2>([&](auto rb_c) {
+    constexpr int RBI = decltype(rb_c)::value;
+    const int row_ld = min(wrow0 + 32 * RBI + c, Lq - 1);
+    const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
+    u32x4 qv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qv[s] = *reinterpret_cast<const u32x4*>(qp + 16 * s);
+    static_for<0, 8>([&](auto s_c) {
+      constexpr int S = decltype(s_c)::value;
+      const u32 w0 = qv[S][0], w1 = qv[S][1], w2 = qv[S][2], w3 = qv[S][3];
+      acc_write<128 + 32 * RBI + 4 * S + 0>(__builtin_bit_cast(float, w0));
+      acc_write<128 + 32 * RBI + 4 * S + 1>(__builtin_bit_cast(float, w1));
+      acc_write<128 + 32 * RBI + 4 * S + 2>(__builtin_bit_cast(float, w2));
+      acc_write<128 + 32 * RBI + 4 * S + 3>(__builtin_bit_cast(float, w3));
+    });
+  });
+  static_for<0, 128>([&](auto r_c) { acc_write<decltype(r_c)::value>(0.f); });
+  asm volatile("s_nop 3");
+
+  const int last_row = min(q0 + BM - 1, Lq - 1);
+  const int max_key = min(last_row + coff, Lk - 1);
+  const int ntiles = max_key >= 0 ? max_key / BN + 1 : 0;      // tiles the workgroup walks
+  // tiles this wave takes part in: those that start at or below its last row's limit
+  int nact = 0;
+  if (wrow0 < Lq && wrow0 + 63 + coff >= 0) nact = min(ntiles, ((wrow0 + 63 + coff) >> 6) + 1);
+
+  // ---- LDS-DMA staging: wave w moves pieces w, w+4, w+8, w+12 (1 KiB = 4 tile rows each)
+  const int32_t* bt_row = PAGED ? p.block_table + static_cast<int64_t>(b) * p.bt_stride : nullptr;
+  const uint32_t k_row_bytes = static_cast<uint32_t>(p.k_stride0) * 2u;
+  const uint32_t v_row_bytes = static_cast<uint32_t>(p.v_stride0) * 2u;
+  const int lrow = lane >> 4;
+  const int lchunk = (lane & 15) ^ ((lrow << 2) | (wave & 3));   // swizzle on the source side
+  const uint32_t colb = static_cast<uint32_t>(kvh * kHeadDim + 8 * lchunk) * 2u;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds3));
+  // per-lane byte offset of this lane's 16 bytes inside a tile, for each of the wave's 4 pieces
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    koff[i] = static_cast<uint32_t>(4 * (wave + NW * i) + lrow) * k_row_bytes + colb;
+    voff[i] = static_cast<uint32_t>(4 * (wave + NW * i) + lrow) * v_row_bytes + colb;
+  }
+  // global address of the first row of a tile (wave-uniform)
+  auto tile_base = [&](int tile, const uint16_t* src, uint32_t row_bytes) -> const char* {
+    const int kt0 = tile * BN;
+    int64_t base_row;
+    if constexpr (PAGED) {
+      const int blk = bt_row[kt0 / p.block_size];
+      base_row = static_cast<int64_t>(blk) * p.block_size + (kt0 % p.block_size);
+    } else {
+      base_row = static_cast<int64_t>(k_start) + kt0;
+    }
+    return reinterpret_cast<const char*>(src) + base_row * row_bytes;
+  };
+  // piece I of a tile: 1 KiB, global (uniform base + per-lane offset) -> LDS (lane-linear at dst).
+  // A tile that runs past the sequence end re-reads the sequence's last row there (masked later).
+  auto dma_piece = [&](const char* tb, int tile, uint32_t row_bytes, const uint32_t (&off)[4], int slot_off, auto i_c) {
+    constexpr int I = decltype(i_c)::value;
+    const int piece = wave + NW * I;
+    uint32_t o = off[I];
+    const int last = Lk - 1 - tile * BN;
+    if (last < BN - 1) o = static_cast<uint32_t>(min(4 * piece + lrow, last)) * row_bytes + colb;
+    const uint32_t dst = lds_base + static_cast<uint32_t>(slot_off + 1024 * piece);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o), "s"(tb), "s"(dst) : "memory");
+  };
+  auto dma_tile = [&](int tile, const uint16_t* src, uint32_t row_bytes, const uint32_t (&off)[4], int slot_off) {
+    const char* tb = tile_base(tile, src, row_bytes);
+    static_for<0, 4>([&](auto i_c) { dma_piece(tb, tile, row_bytes, off, slot_off, i_c); });
+  };
+  auto dma_wait_and_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  const float cexp = p.scale_log2e;
+  const float defer_raw = kDeferLog2 / cexp;
+
+  // ---- LDS read addresses inside slot 0 of K / of V (see prefill_attn_kernel)
+  const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
+  const int gi = lane >> 4;
+  const int tq = (lane & 15) >> 2;
+  const int tp = lane & 3;
+  lds_byte* kaddr[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) kaddr[s] = lds3 + 256 * c + 16 * ((2 * s + h) ^ xr);
+  lds_byte* vaddr[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int second = 0; second < 2; ++second) {
+      const int row = 8 * second + 4 * (gi >> 1) + tq;
+      const int ch = 4 * dt + 2 * (gi & 1) + (tp >> 1);
+      vaddr[dt][second] = lds3 + lds_off(row, ch) + 8 * (tp & 1);   // + V slot offset at the read
+    }
+  // K fragments of d-steps S0 .. S0+3 of a 32-key half
+  auto load_k4 = [&](bf16x8 (&kf)[4], int byte_off, auto s0_c) {
+    constexpr int S0 = decltype(s0_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      kf[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kaddr[S0 + j] + byte_off);
+  };
+  // V^T fragments of one 16-key step (four 32-column blocks)
+  auto load_v4 = [&](bf16x8 (&vf)[4], int byte_off) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int second = 0; second < 2; ++second) {
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(vaddr[dt][second] + byte_off));
+        vf[dt][4 * second + 0] = t[0];
+        vf[dt][4 * second + 1] = t[1];
+        vf[dt][4 * second + 2] = t[2];
+        vf[dt][4 * second + 3] = t[3];
+      }
+  };
+
+  LV_STAMP_DECL
+  // ---- softmax state
+  f32x16 S[2][2][2];        // [tile parity][32-key half][row block]
+  u32 P[2][2][2][8];        // [tile parity][32-key half][row block] two bf16 per dword
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+  float mc[2] = {0.f, 0.f};             // running max * scale * log2(e) the exponentials are taken against
+  float pend_alpha[2] = {1.f, 1.f};
+  bool pend[2] = {false, false};
+  float ps[2] = {0.f, 0.f};             // row-sum shares collected since the last fold into l_run
+
+  // The 64 probabilities a lane owes per tile (element e: 32-key half e >> 5, row block
+  // (e >> 4) & 1, score register e & 15) go through a three-stage pipeline, one stage per MFMA gap,
+  // so that no instruction in a gap waits for another one of the same gap:
+  //   gap g    t  = S[e] * c - m * c
+  //   gap g+1  pe = exp2(t)
+  //   gap g+2  row sum += pe; an odd element is packed with its even partner into one dword
+  float st_t = 0.f, st_pe = 0.f, st_even = 0.f;   // stage registers
+  auto stream_step = [&](f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto e_c) {
+    constexpr int E = decltype(e_c)::value;       // 0..65 (64, 65 drain the pipeline)
+    if constexpr (E >= 2) {                       // third stage of element E - 2
+      constexpr int E2 = E - 2, RB2 = (E2 >> 4) & 1, R2 = E2 & 15;
+      ps[RB2] += st_pe;
+      if constexpr ((R2 & 1) == 0) {
+        st_even = st_pe;
+      } else {
+        bf16x2_t pk;
+        pk[0] = static_cast<__bf16>(st_even);
+        pk[1] = static_cast<__bf16>(st_pe);
+        pw[E2 >> 5][RB2][R2 >> 1] = __builtin_bit_cast(u32, pk);
+        asm volatile("" : "+v"(pw[E2 >> 5][RB2][R2 >> 1]));
+      }
+      asm volatile("" : "+v"(ps[RB2]), "+v"(st_even));
+    }
+    if constexpr (E >= 1 && E <= 64) {            // second stage of element E - 1
+      st_pe = __builtin_amdgcn_exp2f(st_t);
+      asm volatile("" : "+v"(st_pe));
+    }
+    if constexpr (E < 64) {                       // first stage of element E
+      constexpr int RB0 = (E >> 4) & 1;
+      st_t = fmaf(sc[E >> 5][RB0][E & 15], cexp, -mc[RB0]);
+      asm volatile("" : "+v"(st_t));
+    }
+  };
+  auto p_frag = [](const u32 (&pw)[8], int ks) -> bf16x8 {
+    u32x4 t;
+    t[0] = pw[4 * ks + 0]; t[1] = pw[4 * ks + 1]; t[2] = pw[4 * ks + 2]; t[3] = pw[4 * ks + 3];
+    return __builtin_bit_cast(bf16x8, t);
+  };
+  auto max16 = [](const f32x16& s) -> float {
+    float a[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a[j]) : "v"(s[3 * j]), "v"(s[3 * j + 1]), "v"(s[3 * j + 2]));
+    float b0, b1;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(a[3]), "v"(a[4]), "v"(s[15]));
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(b0), "v"(b1));
+    return m;
+  };
+  // causal mask of one tile's scores (diagonal tiles only; wave-uniform test)
+  auto mask_tile = [&](int kt0, f32x16 (&sc)[2][2]) {
+    if (kt0 + 63 > wrow0 + coff) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (key > my_lim0) sc[0][0][r] = -INFINITY;
+        if (key + 32 > my_lim0) sc[1][0][r] = -INFINITY;
+        if (key > my_lim1) sc[0][1][r] = -INFINITY;
+        if (key + 32 > my_lim1) sc[1][1][r] = -INFINITY;
+      }
+    }
+  };
+  // row maximum of a tile for row block rb, running-max decision (deferred rescale)
+  auto decide = [&](f32x16 (&sc)[2][2], auto rb_c) {
+    constexpr int RBI = decltype(rb_c)::value;
+    float mx;
+    {
+      const float m0 = max16(sc[0][RBI]), m1 = max16(sc[1][RBI]);
+      asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(m0), "v"(m1));
+    }
+    mx = pair32_max(mx);
+    if (__builtin_amdgcn_ballot_w64(mx - m_run[RBI] > defer_raw) != 0) {
+      const float m_new = fmaxf(m_run[RBI], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run[RBI] - m_use) * cexp);
+      m_run[RBI] = m_new;
+      l_run[RBI] = (l_run[RBI] + ps[RBI]) * alpha;   // everything summed so far is at the old scale
+      ps[RBI] = 0.f;
+      pend_alpha[RBI] = alpha;
+      pend[RBI] = true;
+      mc[RBI] = m_use * cexp;
+    }
+  };
+  auto apply_pending = [&]() {
+    static_for<0, 2>([&](auto rb_c) {
+      constexpr int RBI = decltype(rb_c)::value;
+      if (pend[RBI]) {        // wave-uniform (set under a ballot)
+        asm volatile("s_nop 15");
+        static_for<0, 64>([&](auto r_c) { acc_scale<64 * RBI + decltype(r_c)::value>(pend_alpha[RBI]); });
+        asm volatile("s_nop 3");
+        pend[RBI] = false;
+      }
+    });
+  };
+  auto settle = [&](f32x16 (&sc)[2][2]) {
+    asm volatile("s_nop 15" : "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]), "+v"(sc[1][1]));
+  };
+
+  // QK phase: scores of the tile in K slot KS into sc; vector work for gap g from fill(IntC<g>)
+  auto qk_phase = [&](f32x16 (&sc)[2][2], auto kslot_c, auto&& fill) {
+    constexpr int KOFF = decltype(kslot_c)::value * kTileBytes;
+    bf16x8 ka[4], kb[4];
+    load_k4(ka, KOFF, IntC<0>{});
+    load_k4(kb, KOFF, IntC<4>{});
+    static_for<0, 2>([&](auto half_c) {
+      constexpr int HALF = decltype(half_c)::value;
+      static_for<0, 8>([&](auto s_c) {
+        constexpr int SI = decltype(s_c)::value;
+        constexpr int G0 = 16 * HALF + 2 * SI;
+        const bf16x8& kf = SI < 4 ? ka[SI & 3] : kb[SI & 3];
+        mfma_s<128 + 4 * SI, SI == 0>(sc[HALF][0], kf);
+        fill(IntC<G0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_s<160 + 4 * SI, SI == 0>(sc[HALF][1], kf);
+        fill(IntC<G0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HALF == 0 && SI == 3) load_k4(ka, KOFF + 8192, IntC<0>{});
+        if constexpr (HALF == 0 && SI == 7) load_k4(kb, KOFF + 8192, IntC<4>{});
+      });
+    });
+  };
+  // PV phase: O += V^T P for the tile in V slot VS with probabilities pr; fill as above
+  auto pv_phase = [&](const u32 (&pr)[2][2][8], auto vslot_c, auto&& fill) {
+    constexpr int VOFF = decltype(vslot_c)::value * kTileBytes;
+    bf16x8 va[4], vb[4];
+    load_v4(va, VOFF);
+    load_v4(vb, VOFF + 4096);
+    asm volatile("s_nop 1");     // P was written by vector instructions
+    static_for<0, 4>([&](auto ks_c) {
+      constexpr int KS = decltype(ks_c)::value;     // 16-key step: half KS >> 1, step KS & 1
+      bf16x8 pf0 = p_frag(pr[KS >> 1][0], KS & 1);
+      bf16x8 pf1 = p_frag(pr[KS >> 1][1], KS & 1);
+      // the fragments may have been gathered by vector moves just now: wait states before an
+      // MFMA reads them
+      asm volatile("s_nop 1" : "+v"(pf0), "+v"(pf1));
+      static_for<0, 4>([&](auto dt_c) {
+        constexpr int DT = decltype(dt_c)::value;
+        constexpr int G0 = 8 * KS + 2 * DT;
+        const bf16x8& vf = (KS & 1) ? vb[DT] : va[DT];
+        mfma_o<16 * DT>(vf, pf0);
+        fill(IntC<G0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_o<64 + 16 * DT>(vf, pf1);
+        fill(IntC<G0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (KS == 0) load_v4(va, VOFF + 8192);
+      if constexpr (KS == 1) load_v4(vb, VOFF + 12288);
+    });
+  };
+
+  // Vector work of the PV phase (or of the prologue, stand-alone) for the tile whose scores were
+  // just formed: gap 0 settles and masks them, gaps 1 and 2 take the row maxima and the
+  // running-max decisions, gaps 3..30 the first stage of elements 0..27.
+  constexpr int kSplit = 28;     // elements started in the PV phase; the rest start in the QK phase
+  auto start_fill = [&](int kt0, f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto g_c) {
+    constexpr int GP = decltype(g_c)::value;
+    if constexpr (GP == 0) { settle(sc); mask_tile(kt0, sc); }
+    if constexpr (GP == 1) decide(sc, IntC<0>{});
+    if constexpr (GP == 2) decide(sc, IntC<1>{});
+    if constexpr (GP >= 3 && GP < 3 + kSplit) stream_step(sc, pw, IntC<GP - 3>{});
+  };
+  // Vector work of the QK phase: elements kSplit..63 of the previous tile's scores (two per gap
+  // until the 32 gaps suffice), then the two steps that drain the pipeline.
+  auto finish_fill = [&](f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto g_c) {
+    constexpr int GP = decltype(g_c)::value;
+    constexpr int kLeft = 64 - kSplit;            // 36
+    constexpr int kDouble = kLeft - 32;           // gaps that take two steps
+    if constexpr (GP < kDouble) {
+      stream_step(sc, pw, IntC<kSplit + 2 * GP>{});
+      stream_step(sc, pw, IntC<kSplit + 2 * GP + 1>{});
+    } else {
+      stream_step(sc, pw, IntC<kSplit + kDouble + GP>{});
+    }
+    if constexpr (GP == 31) {
+      stream_step(sc, pw, IntC<64>{});
+      stream_step(sc, pw, IntC<65>{});
+    }
+  };
+
+  // iteration i (parity PAR): QK(i+1) beside the second half of softmax(i), then PV(i) beside the
+  // first half of softmax(i+1)
+  auto iteration = [&](int i, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value, NPAR = PAR ^ 1;
+    // K(i+2) -> K slot PAR (K(i) was read an iteration ago), V(i+1) -> V slot NPAR
+    const bool k_on = i + 2 < ntiles, v_on = i + 1 < ntiles;
+    const char* ktb = k_on ? tile_base(i + 2, p.k, k_row_bytes) : nullptr;
+    const char* vtb = v_on ? tile_base(i + 1, p.v, v_row_bytes) : nullptr;
+    LV_STAMP(3)
+    if (i < nact) {
+      LV_STAMP_COUNT
+      qk_phase(S[NPAR], IntC<NPAR>{}, [&](auto g_c) {
+        constexpr int GP = decltype(g_c)::value;
+        finish_fill(S[PAR], P[PAR], g_c);
+        // one DMA piece in every fourth gap
+        if constexpr (GP % 4 == 2 && GP < 16) { if (k_on) dma_piece(ktb, i + 2, k_row_bytes, koff, PAR * kTileBytes, IntC<GP / 4>{}); }
+        if constexpr (GP % 4 == 2 && GP >= 16) { if (v_on) dma_piece(vtb, i + 1, v_row_bytes, voff, (2 + NPAR) * kTileBytes, IntC<GP / 4 - 4>{}); }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      LV_STAMP(4)
+      pv_phase(P[PAR], IntC<2 + PAR>{}, [&](auto g_c) { start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c); });
+      __builtin_amdgcn_sched_barrier(0);
+      LV_STAMP(5)
+      apply_pending();
+    } else {
+      if (k_on) static_for<0, 4>([&](auto i_c) { dma_piece(ktb, i + 2, k_row_bytes, koff, PAR * kTileBytes, i_c); });
+      if (v_on) static_for<0, 4>([&](auto i_c) { dma_piece(vtb, i + 1, v_row_bytes, voff, (2 + NPAR) * kTileBytes, i_c); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LV_STAMP(1)
+    __syncthreads();
+    LV_STAMP(0)
+  };
+
+  if (ntiles > 0) {
+    dma_tile(0, p.k, k_row_bytes, koff, 0);
+    dma_tile(0, p.v, v_row_bytes, voff, 2 * kTileBytes);
+    if (ntiles > 1) dma_tile(1, p.k, k_row_bytes, koff, kTileBytes);
+    dma_wait_and_barrier();
+    if (nact > 0) {
+      qk_phase(S[0], IntC<0>{}, [&](auto) {});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 32>([&](auto g_c) {
+        start_fill(0, S[0], P[0], g_c);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      apply_pending();     // first decision: alpha = 0 on a zero accumulator; clears the flag
+    }
+    __syncthreads();       // every wave has read K(0) before iteration 0 overwrites its slot
+    LV_STAMP(14)
+    for (int i = 0; i < ntiles; i += 2) {
+      iteration(i, IntC<0>{});
+      if (i + 1 < ntiles) iteration(i + 1, IntC<1>{});
+    }
+  }
+
+  LV_STAMP_FLUSH
+  // ---- epilogue: normalise and store (d = 32*dt + (r&3) + 8*(r>>2) + 4*h)
+  asm volatile("s_nop 15");
+  static_for<0, 2>([&](auto rb_c) {
+    constexpr int RBI = decltype(rb_c)::value;
+    const float l_lane = l_run[RBI] + ps[RBI];
+    const float l_tot = l_lane + __shfl_xor(l_lane, 32);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    const int my_row = wrow0 + 32 * RBI + c;
+    uint16_t* op = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim + 4 * h;
+    static_for<0, 4>([&](auto dt_c) {
+      static_for<0, 4>([&](auto rg_c) {
+        constexpr int DT = decltype(dt_c)::value, RG = decltype(rg_c)::value;
+        constexpr int R0 = 64 * RBI + 16 * DT + 4 * RG;
+        u32x2 w;
+        w[0] = pack_bf16x2(acc_read<R0 + 0>() * inv, acc_read<R0 + 1>() * inv);
+        w[1] = pack_bf16x2(acc_read<R0 + 2>() * inv, acc_read<R0 + 3>() * inv);
+        if (my_row < Lq) *reinterpret_cast<u32x2*>(op + 32 * DT + 8 * RG) = w;
+      });
+    });
+  });
+}
+
+template <bool PAGED>
+static void launch_w64(const PrefillParams& p, hipStream_t stream) {
+  const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
+  const int64_t total = qtiles * p.num_heads * p.batch;
+  hipLaunchKernelGGL((prefill_w64_kernel<PAGED>), dim3(static_cast<unsigned>(total)), dim3(256), 0, stream, p);
+}
+
 template <bool PAGED>
 static void launch_pp(const PrefillParams& p, hipStream_t stream) {
   const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
@@ -1227,7 +1677,9 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   const int force = env_cfg ? atoi(env_cfg) : -1;
   const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q >= 1024 ? 1 : 0));
   const int dma = env_dma ? atoi(env_dma) : 0;
-  if (cfg == 3) {
+  if (cfg == 4) {
+    if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
+  } else if (cfg == 3) {
     if (p.block_table) launch_cfg<true, 4, 2, false>(p, stream); else launch_cfg<false, 4, 2, false>(p, stream);
   } else if (cfg == 2) {
     if (p.block_table) launch_pp<true>(p, stream); else launch_pp<false>(p, stream);

@@ -4,7 +4,7 @@
 set -e
 export LV_PREFILL_CFG=$1
 OUT=$2
-BIN=$PWD/tools/prefill_abl0
+BIN=$PWD/tools/prefill_p0
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/a -o a --output-format csv -- $BIN > /dev/null 2>&1

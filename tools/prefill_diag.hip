@@ -75,8 +75,11 @@ int main(int argc, char** argv) {
   const char* names_pp[16] = {"L_K: rescale + exp half", "C_QK: 16 MFMA | exp", "L_V: mask, max, decision",
                               "C_PV: 16 MFMA | exp", "barrier after L_K", "barrier after C_QK", "barrier after L_V",
                               "barrier after C_PV", "L_V: K publish + loads", "L_V: V reads (+wait)", "L_K: V publish + loads", "L_K: K reads (+wait)", "-", "-", "-", "-"};
+  const char* names_w64[16] = {"barrier", "pending rescale + DMA wait", "-", "DMA issue", "QK phase (32 MFMA | exp)",
+                               "PV phase (32 MFMA | max, exp)", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"};
   const char* cfg = getenv("LV_PREFILL_CFG");
   if (cfg && atoi(cfg) == 2) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
+  if (cfg && atoi(cfg) == 4) { for (int i = 0; i < 16; ++i) names[i] = names_w64[i]; tot -= seg[14]; seg[14] = 0; }
   if (seg[13] > 0) printf("in-kernel clock: %.0f MHz (shader ticks per 100 MHz reference tick, averaged over waves)\n", 100.0 * seg[12] / seg[13]);
   tot -= seg[12] + seg[13]; seg[12] = seg[13] = 0;
   tot -= seg[15];
