@@ -118,6 +118,11 @@ __device__ __forceinline__ float pair32_max(float x) {
   "a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159", \
   "a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175", \
   "a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
+#define LV_ACC_CLOBBERS_192_255 \
+  "a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207", \
+  "a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223", \
+  "a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239", \
+  "a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -1213,15 +1218,20 @@ void prefill_pp_kernel(const PrefillParams p) {
 //   PV phase   O += V(i)^T P(i)             beside   row maxima of S(i+1), running-max decision,
 //                                                    P(i+1) first half = exp2(S(i+1) keys 0-31)
 // A rescale decided for tile i+1 during PV(i) scales l at once and O after PV(i) has been added
-// (P(i) was formed at the old scale). K/V tiles arrive by LDS-DMA (global_load_lds, 1 KiB per wave
-// instruction, swizzle applied to the per-lane source address), K two tiles ahead and V one, each
-// in a 2-slot ring; the DMA is inline asm with its own vmcnt(0) before the barrier, so hipcc
-// neither waits for it early nor orders LDS reads behind it.
+// (P(i) was formed at the old scale). K and V tiles are staged through registers into 2-slot LDS
+// rings, each tile loaded one iteration before it is written and written one iteration before it
+// is read: iteration i writes V(i+1) and requests V(i+2) in its QK phase, writes K(i+2) and
+// requests K(i+3) in its PV phase. (LDS-DMA, which needs no registers, measured ~100 issue cycles
+// per 1 KiB piece inside these phases, 8 pieces per wave and tile.)
 template <bool PAGED>
 __global__ __launch_bounds__(256, 1)
 void prefill_w64_kernel(const PrefillParams p) {
   constexpr int NW = 4;
   constexpr int BM = 64 * NW;
+  // Accumulator registers owned by the asm statements: O^T of row block rb at a[kAccO + 64 rb ..],
+  // Q^T fragments of row block rb at a[kAccQ + 32 rb ..]. a[0:63] are left to hipcc, which places
+  // the staging registers there (global loads and LDS stores take accumulator registers directly).
+  constexpr int kAccO = 64, kAccQ = 192;
   // K slot s at s * kTileBytes, V slot s at (2 + s) * kTileBytes
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTileBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
@@ -1252,7 +1262,7 @@ void prefill_w64_kernel(const PrefillParams p) {
   const int my_lim1 = my_lim0 + 32;
 
   // ---- Q^T fragments -> a[128:191]; O^T a[0:127] = 0
-  asm volatile("" ::: LV_ACC_CLOBBERS_0_63, LV_ACC_CLOBBERS_64_127, LV_ACC_CLOBBERS_128_191);
+  asm volatile("" ::: LV_ACC_CLOBBERS_64_127, LV_ACC_CLOBBERS_128_191, LV_ACC_CLOBBERS_192_255);
   static_for<0, 2>([&](auto rb_c) {
     constexpr int RBI = decltype(rb_c)::value;
     const int row_ld = min(wrow0 + 32 * RBI + c, Lq - 1);
@@ -1263,13 +1273,13 @@ void prefill_w64_kernel(const PrefillParams p) {
     static_for<0, 8>([&](auto s_c) {
       constexpr int S = decltype(s_c)::value;
       const u32 w0 = qv[S][0], w1 = qv[S][1], w2 = qv[S][2], w3 = qv[S][3];
-      acc_write<128 + 32 * RBI + 4 * S + 0>(__builtin_bit_cast(float, w0));
-      acc_write<128 + 32 * RBI + 4 * S + 1>(__builtin_bit_cast(float, w1));
-      acc_write<128 + 32 * RBI + 4 * S + 2>(__builtin_bit_cast(float, w2));
-      acc_write<128 + 32 * RBI + 4 * S + 3>(__builtin_bit_cast(float, w3));
+      acc_write<kAccQ + 32 * RBI + 4 * S + 0>(__builtin_bit_cast(float, w0));
+      acc_write<kAccQ + 32 * RBI + 4 * S + 1>(__builtin_bit_cast(float, w1));
+      acc_write<kAccQ + 32 * RBI + 4 * S + 2>(__builtin_bit_cast(float, w2));
+      acc_write<kAccQ + 32 * RBI + 4 * S + 3>(__builtin_bit_cast(float, w3));
     });
   });
-  static_for<0, 128>([&](auto r_c) { acc_write<decltype(r_c)::value>(0.f); });
+  static_for<0, 128>([&](auto r_c) { acc_write<kAccO + decltype(r_c)::value>(0.f); });
   asm volatile("s_nop 3");
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
@@ -1295,7 +1305,8 @@ void prefill_w64_kernel(const PrefillParams p) {
     voff[i] = static_cast<uint32_t>(4 * (wave + NW * i) + lrow) * v_row_bytes + colb;
   }
   // global address of the first row of a tile (wave-uniform)
-  auto tile_base = [&](int tile, const uint16_t* src, uint32_t row_bytes) -> const char* {
+  typedef const __attribute__((address_space(1))) char* gptr;
+  auto tile_base = [&](int tile, const uint16_t* src, uint32_t row_bytes) -> gptr {
     const int kt0 = tile * BN;
     int64_t base_row;
     if constexpr (PAGED) {
@@ -1304,29 +1315,47 @@ void prefill_w64_kernel(const PrefillParams p) {
     } else {
       base_row = static_cast<int64_t>(k_start) + kt0;
     }
-    return reinterpret_cast<const char*>(src) + base_row * row_bytes;
+    // wave-uniform by construction; said so to hipcc, which must hold it in scalar registers
+    const uint64_t a = reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(src) + base_row * row_bytes);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+    // a pointer made from an integer is a flat pointer to hipcc; flat loads count in lgkmcnt as
+    // well and would tie every LDS wait to the staging loads, so name the global address space
+    return reinterpret_cast<gptr>((static_cast<uint64_t>(hi) << 32) | lo);
   };
   // piece I of a tile: 1 KiB, global (uniform base + per-lane offset) -> LDS (lane-linear at dst).
-  // A tile that runs past the sequence end re-reads the sequence's last row there (masked later).
-  auto dma_piece = [&](const char* tb, int tile, uint32_t row_bytes, const uint32_t (&off)[4], int slot_off, auto i_c) {
+  // Register staging, one set of four 16-byte registers for K and one for V: a tile's four pieces
+  // are loaded (global -> registers, uniform base + per-lane offset) a whole iteration before they
+  // are written to LDS (lane-linear inside each 1 KiB piece; the swizzle is in the source offset):
+  // the loads measured ~4000 cycles from issue to data under this kernel's own traffic.
+  u32x4 kst[4], vst[4];
+  auto stage_load = [&](u32x4 (&st)[4], gptr tb, const uint32_t (&off)[4], auto i_c) {
     constexpr int I = decltype(i_c)::value;
-    const int piece = wave + NW * I;
-    uint32_t o = off[I];
+    st[I] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(tb + off[I]);
+  };
+  auto stage_write = [&](const u32x4 (&st)[4], int slot_off, auto i_c) {
+    constexpr int I = decltype(i_c)::value;
+    *reinterpret_cast<u32x4*>(lds + slot_off + 1024 * NW * I + 1024 * wave + 16 * lane) = st[I];
+  };
+  // The tile that runs past the sequence end is the last one the workgroup loads: from then on
+  // the offsets point rows past the end at the sequence's last row (masked later).
+  auto clamp_offsets = [&](int tile) {
     const int last = Lk - 1 - tile * BN;
-    if (last < BN - 1) o = static_cast<uint32_t>(min(4 * piece + lrow, last)) * row_bytes + colb;
-    const uint32_t dst = lds_base + static_cast<uint32_t>(slot_off + 1024 * piece);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(o), "s"(tb), "s"(dst) : "memory");
+    if (last < BN - 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t r = static_cast<uint32_t>(min(4 * (wave + NW * i) + lrow, last));
+        koff[i] = r * k_row_bytes + colb;
+        voff[i] = r * v_row_bytes + colb;
+      }
+    }
   };
-  auto dma_tile = [&](int tile, const uint16_t* src, uint32_t row_bytes, const uint32_t (&off)[4], int slot_off) {
-    const char* tb = tile_base(tile, src, row_bytes);
-    static_for<0, 4>([&](auto i_c) { dma_piece(tb, tile, row_bytes, off, slot_off, i_c); });
+  auto stage_tile_now = [&](int tile, const uint16_t* src, uint32_t row_bytes, const uint32_t (&off)[4], int slot_off) {
+    gptr tb = tile_base(tile, src, row_bytes);
+    static_for<0, 4>([&](auto i_c) { stage_load(kst, tb, off, i_c); });
+    static_for<0, 4>([&](auto i_c) { stage_write(kst, slot_off, i_c); });
   };
-  auto dma_wait_and_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
+
 
   const float cexp = p.scale_log2e;
   const float defer_raw = kDeferLog2 / cexp;
@@ -1444,25 +1473,44 @@ void prefill_w64_kernel(const PrefillParams p) {
       }
     }
   };
-  // row maximum of a tile for row block rb, running-max decision (deferred rescale)
-  auto decide = [&](f32x16 (&sc)[2][2], auto rb_c) {
-    constexpr int RBI = decltype(rb_c)::value;
-    float mx;
-    {
-      const float m0 = max16(sc[0][RBI]), m1 = max16(sc[1][RBI]);
-      asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(m0), "v"(m1));
+  // row maxima of a tile for both row blocks (independent chains, interleaved), then the
+  // running-max decisions (deferred rescale) under one wave-uniform test
+  auto fmax_raw = [](float x, float y) -> float {     // v_max_f32 without canonicalising moves
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    return m;
+  };
+  auto decide_both = [&](f32x16 (&sc)[2][2]) {
+    float mx[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) mx[rb] = fmax_raw(max16(sc[0][rb]), max16(sc[1][rb]));
+    unsigned sw0[2], sw1[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const unsigned xb = __builtin_bit_cast(unsigned, mx[rb]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      sw0[rb] = sw[0];
+      sw1[rb] = sw[1];
     }
-    mx = pair32_max(mx);
-    if (__builtin_amdgcn_ballot_w64(mx - m_run[RBI] > defer_raw) != 0) {
-      const float m_new = fmaxf(m_run[RBI], mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run[RBI] - m_use) * cexp);
-      m_run[RBI] = m_new;
-      l_run[RBI] = (l_run[RBI] + ps[RBI]) * alpha;   // everything summed so far is at the old scale
-      ps[RBI] = 0.f;
-      pend_alpha[RBI] = alpha;
-      pend[RBI] = true;
-      mc[RBI] = m_use * cexp;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+      mx[rb] = fmax_raw(__builtin_bit_cast(float, sw0[rb]), __builtin_bit_cast(float, sw1[rb]));
+    const bool need0 = mx[0] - m_run[0] > defer_raw, need1 = mx[1] - m_run[1] > defer_raw;
+    if (__builtin_amdgcn_ballot_w64(need0 || need1) != 0) {
+      static_for<0, 2>([&](auto rb_c) {
+        constexpr int RBI = decltype(rb_c)::value;
+        if (__builtin_amdgcn_ballot_w64(RBI == 0 ? need0 : need1) != 0) {
+          const float m_new = fmaxf(m_run[RBI], mx[RBI]);
+          const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+          const float alpha = __builtin_amdgcn_exp2f((m_run[RBI] - m_use) * cexp);
+          m_run[RBI] = m_new;
+          l_run[RBI] = (l_run[RBI] + ps[RBI]) * alpha;   // everything summed so far is at the old scale
+          ps[RBI] = 0.f;
+          pend_alpha[RBI] = alpha;
+          pend[RBI] = true;
+          mc[RBI] = m_use * cexp;
+        }
+      });
     }
   };
   auto apply_pending = [&]() {
@@ -1470,7 +1518,7 @@ void prefill_w64_kernel(const PrefillParams p) {
       constexpr int RBI = decltype(rb_c)::value;
       if (pend[RBI]) {        // wave-uniform (set under a ballot)
         asm volatile("s_nop 15");
-        static_for<0, 64>([&](auto r_c) { acc_scale<64 * RBI + decltype(r_c)::value>(pend_alpha[RBI]); });
+        static_for<0, 64>([&](auto r_c) { acc_scale<kAccO + 64 * RBI + decltype(r_c)::value>(pend_alpha[RBI]); });
         asm volatile("s_nop 3");
         pend[RBI] = false;
       }
@@ -1492,10 +1540,10 @@ void prefill_w64_kernel(const PrefillParams p) {
         constexpr int SI = decltype(s_c)::value;
         constexpr int G0 = 16 * HALF + 2 * SI;
         const bf16x8& kf = SI < 4 ? ka[SI & 3] : kb[SI & 3];
-        mfma_s<128 + 4 * SI, SI == 0>(sc[HALF][0], kf);
+        mfma_s<kAccQ + 4 * SI, SI == 0>(sc[HALF][0], kf);
         fill(IntC<G0>{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma_s<160 + 4 * SI, SI == 0>(sc[HALF][1], kf);
+        mfma_s<kAccQ + 32 + 4 * SI, SI == 0>(sc[HALF][1], kf);
         fill(IntC<G0 + 1>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HALF == 0 && SI == 3) load_k4(ka, KOFF + 8192, IntC<0>{});
@@ -1504,11 +1552,8 @@ void prefill_w64_kernel(const PrefillParams p) {
     });
   };
   // PV phase: O += V^T P for the tile in V slot VS with probabilities pr; fill as above
-  auto pv_phase = [&](const u32 (&pr)[2][2][8], auto vslot_c, auto&& fill) {
+  auto pv_phase = [&](const u32 (&pr)[2][2][8], auto vslot_c, bf16x8 (&va)[4], bf16x8 (&vb)[4], auto&& fill) {
     constexpr int VOFF = decltype(vslot_c)::value * kTileBytes;
-    bf16x8 va[4], vb[4];
-    load_v4(va, VOFF);
-    load_v4(vb, VOFF + 4096);
     asm volatile("s_nop 1");     // P was written by vector instructions
     static_for<0, 4>([&](auto ks_c) {
       constexpr int KS = decltype(ks_c)::value;     // 16-key step: half KS >> 1, step KS & 1
@@ -1521,10 +1566,10 @@ void prefill_w64_kernel(const PrefillParams p) {
         constexpr int DT = decltype(dt_c)::value;
         constexpr int G0 = 8 * KS + 2 * DT;
         const bf16x8& vf = (KS & 1) ? vb[DT] : va[DT];
-        mfma_o<16 * DT>(vf, pf0);
+        mfma_o<kAccO + 16 * DT>(vf, pf0);
         fill(IntC<G0>{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma_o<64 + 16 * DT>(vf, pf1);
+        mfma_o<kAccO + 64 + 16 * DT>(vf, pf1);
         fill(IntC<G0 + 1>{});
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -1534,14 +1579,13 @@ void prefill_w64_kernel(const PrefillParams p) {
   };
 
   // Vector work of the PV phase (or of the prologue, stand-alone) for the tile whose scores were
-  // just formed: gap 0 settles and masks them, gaps 1 and 2 take the row maxima and the
-  // running-max decisions, gaps 3..30 the first stage of elements 0..27.
+  // just formed: gap 0 settles and masks them, gap 1 takes the row maxima and the running-max
+  // decisions, gaps 3..30 the first stage of elements 0..27.
   constexpr int kSplit = 28;     // elements started in the PV phase; the rest start in the QK phase
   auto start_fill = [&](int kt0, f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto g_c) {
     constexpr int GP = decltype(g_c)::value;
     if constexpr (GP == 0) { settle(sc); mask_tile(kt0, sc); }
-    if constexpr (GP == 1) decide(sc, IntC<0>{});
-    if constexpr (GP == 2) decide(sc, IntC<1>{});
+    if constexpr (GP == 1) decide_both(sc);
     if constexpr (GP >= 3 && GP < 3 + kSplit) stream_step(sc, pw, IntC<GP - 3>{});
   };
   // Vector work of the QK phase: elements kSplit..63 of the previous tile's scores (two per gap
@@ -1566,41 +1610,66 @@ void prefill_w64_kernel(const PrefillParams p) {
   // first half of softmax(i+1)
   auto iteration = [&](int i, auto par_c) {
     constexpr int PAR = decltype(par_c)::value, NPAR = PAR ^ 1;
-    // K(i+2) -> K slot PAR (K(i) was read an iteration ago), V(i+1) -> V slot NPAR
-    const bool k_on = i + 2 < ntiles, v_on = i + 1 < ntiles;
-    const char* ktb = k_on ? tile_base(i + 2, p.k, k_row_bytes) : nullptr;
-    const char* vtb = v_on ? tile_base(i + 1, p.v, v_row_bytes) : nullptr;
+    // On entry the V set holds V(i+1) and the K set K(i+2) (requested an iteration ago).
+    // QK phase: V(i+1) -> V slot NPAR (V(i-1) was read an iteration ago), V(i+2) requested.
+    // PV phase: K(i+2) -> K slot PAR (K(i) was read an iteration ago), K(i+3) requested.
+    const bool w1 = i + 1 < ntiles, w2 = i + 2 < ntiles, w3 = i + 3 < ntiles;
+    gptr vtb = w2 ? tile_base(i + 2, p.v, v_row_bytes) : nullptr;
+    gptr ktb = w3 ? tile_base(i + 3, p.k, k_row_bytes) : nullptr;
     LV_STAMP(3)
     if (i < nact) {
       LV_STAMP_COUNT
+      bf16x8 va[4], vb[4];      // V^T fragments of the first two 16-key steps of V(i)
       qk_phase(S[NPAR], IntC<NPAR>{}, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
+        if constexpr (GP < 4) { if (w1) stage_write(vst, (2 + NPAR) * kTileBytes, IntC<GP>{}); }
+        if constexpr (GP >= 4 && GP < 8) { if (w2) stage_load(vst, vtb, voff, IntC<GP - 4>{}); }
+        if constexpr (GP == 26) load_v4(va, (2 + PAR) * kTileBytes);
         finish_fill(S[PAR], P[PAR], g_c);
-        // one DMA piece in every fourth gap
-        if constexpr (GP % 4 == 2 && GP < 16) { if (k_on) dma_piece(ktb, i + 2, k_row_bytes, koff, PAR * kTileBytes, IntC<GP / 4>{}); }
-        if constexpr (GP % 4 == 2 && GP >= 16) { if (v_on) dma_piece(vtb, i + 1, v_row_bytes, voff, (2 + NPAR) * kTileBytes, IntC<GP / 4 - 4>{}); }
       });
       __builtin_amdgcn_sched_barrier(0);
       LV_STAMP(4)
-      pv_phase(P[PAR], IntC<2 + PAR>{}, [&](auto g_c) { start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c); });
+      load_v4(vb, (2 + PAR) * kTileBytes + 4096);
+      pv_phase(P[PAR], IntC<2 + PAR>{}, va, vb, [&](auto g_c) {
+        constexpr int GP = decltype(g_c)::value;
+        if constexpr (GP >= 3 && GP < 7) { if (w2) stage_write(kst, PAR * kTileBytes, IntC<GP - 3>{}); }
+        if constexpr (GP == 7) { if (w3) clamp_offsets(i + 3); }
+        if constexpr (GP >= 7 && GP < 11) { if (w3) stage_load(kst, ktb, koff, IntC<GP - 7>{}); }
+        start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c);
+      });
       __builtin_amdgcn_sched_barrier(0);
       LV_STAMP(5)
       apply_pending();
     } else {
-      if (k_on) static_for<0, 4>([&](auto i_c) { dma_piece(ktb, i + 2, k_row_bytes, koff, PAR * kTileBytes, i_c); });
-      if (v_on) static_for<0, 4>([&](auto i_c) { dma_piece(vtb, i + 1, v_row_bytes, voff, (2 + NPAR) * kTileBytes, i_c); });
+      if (w1) static_for<0, 4>([&](auto i_c) { stage_write(vst, (2 + NPAR) * kTileBytes, i_c); });
+      if (w2) static_for<0, 4>([&](auto i_c) { stage_load(vst, vtb, voff, i_c); });
+      if (w2) static_for<0, 4>([&](auto i_c) { stage_write(kst, PAR * kTileBytes, i_c); });
+      if (w3) {
+        clamp_offsets(i + 3);
+        static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb, koff, i_c); });
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LV_STAMP(1)
     __syncthreads();
     LV_STAMP(0)
   };
 
   if (ntiles > 0) {
-    dma_tile(0, p.k, k_row_bytes, koff, 0);
-    dma_tile(0, p.v, v_row_bytes, voff, 2 * kTileBytes);
-    if (ntiles > 1) dma_tile(1, p.k, k_row_bytes, koff, kTileBytes);
-    dma_wait_and_barrier();
+    clamp_offsets(0);
+    stage_tile_now(0, p.k, k_row_bytes, koff, 0);
+    stage_tile_now(0, p.v, v_row_bytes, voff, 2 * kTileBytes);
+    if (ntiles > 1) {
+      clamp_offsets(1);
+      stage_tile_now(1, p.k, k_row_bytes, koff, kTileBytes);
+      gptr vtb1 = tile_base(1, p.v, v_row_bytes);      // V(1) and K(2) stay in the staging sets
+      static_for<0, 4>([&](auto i_c) { stage_load(vst, vtb1, voff, i_c); });
+    }
+    if (ntiles > 2) {
+      clamp_offsets(2);
+      gptr ktb2 = tile_base(2, p.k, k_row_bytes);
+      static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb2, koff, i_c); });
+    }
+    __syncthreads();
     if (nact > 0) {
       qk_phase(S[0], IntC<0>{}, [&](auto) {});
       __builtin_amdgcn_sched_barrier(0);
@@ -1631,7 +1700,7 @@ void prefill_w64_kernel(const PrefillParams p) {
     static_for<0, 4>([&](auto dt_c) {
       static_for<0, 4>([&](auto rg_c) {
         constexpr int DT = decltype(dt_c)::value, RG = decltype(rg_c)::value;
-        constexpr int R0 = 64 * RBI + 16 * DT + 4 * RG;
+        constexpr int R0 = kAccO + 64 * RBI + 16 * DT + 4 * RG;
         u32x2 w;
         w[0] = pack_bf16x2(acc_read<R0 + 0>() * inv, acc_read<R0 + 1>() * inv);
         w[1] = pack_bf16x2(acc_read<R0 + 2>() * inv, acc_read<R0 + 3>() * inv);

@@ -75,8 +75,8 @@ int main(int argc, char** argv) {
   const char* names_pp[16] = {"L_K: rescale + exp half", "C_QK: 16 MFMA | exp", "L_V: mask, max, decision",
                               "C_PV: 16 MFMA | exp", "barrier after L_K", "barrier after C_QK", "barrier after L_V",
                               "barrier after C_PV", "L_V: K publish + loads", "L_V: V reads (+wait)", "L_K: V publish + loads", "L_K: K reads (+wait)", "-", "-", "-", "-"};
-  const char* names_w64[16] = {"barrier", "pending rescale + DMA wait", "-", "DMA issue", "QK phase (32 MFMA | exp)",
-                               "PV phase (32 MFMA | max, exp)", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"};
+  const char* names_w64[16] = {"barrier", "pending rescale + DMA wait", "-", "tile bases", "QK gaps 17-31",
+                               "PV gaps 17-31", "PV: V reads + gap 0 (settle, mask)", "-", "PV gaps 1-2 (decisions)", "QK: K reads + gap 0", "QK gaps 1-16 (4 DMA)", "PV gaps 3-16", "-", "-", "-", "-"};
   const char* cfg = getenv("LV_PREFILL_CFG");
   if (cfg && atoi(cfg) == 2) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
   if (cfg && atoi(cfg) == 4) { for (int i = 0; i < 16; ++i) names[i] = names_w64[i]; tot -= seg[14]; seg[14] = 0; }
