@@ -1613,17 +1613,20 @@ void prefill_w64_kernel(const PrefillParams p) {
     // On entry the V set holds V(i+1) and the K set K(i+2) (requested an iteration ago).
     // QK phase: V(i+1) -> V slot NPAR (V(i-1) was read an iteration ago), V(i+2) requested.
     // PV phase: K(i+2) -> K slot PAR (K(i) was read an iteration ago), K(i+3) requested.
-    const bool w1 = i + 1 < ntiles, w2 = i + 2 < ntiles, w3 = i + 3 < ntiles;
-    gptr vtb = w2 ? tile_base(i + 2, p.v, v_row_bytes) : nullptr;
-    gptr ktb = w3 ? tile_base(i + 3, p.k, k_row_bytes) : nullptr;
+    // Past the last tile the last tile is requested and written again (into slots nobody reads
+    // any more): the memory operations are then the same in every iteration, with no branch
+    // around them, and hipcc can count its vmcnt waits exactly (a wait for the set loaded an
+    // iteration ago, not for the one requested half an iteration ago).
+    gptr vtb = tile_base(min(i + 2, ntiles - 1), p.v, v_row_bytes);
+    gptr ktb = tile_base(min(i + 3, ntiles - 1), p.k, k_row_bytes);
     LV_STAMP(3)
     if (i < nact) {
       LV_STAMP_COUNT
       bf16x8 va[4], vb[4];      // V^T fragments of the first two 16-key steps of V(i)
       qk_phase(S[NPAR], IntC<NPAR>{}, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
-        if constexpr (GP < 4) { if (w1) stage_write(vst, (2 + NPAR) * kTileBytes, IntC<GP>{}); }
-        if constexpr (GP >= 4 && GP < 8) { if (w2) stage_load(vst, vtb, voff, IntC<GP - 4>{}); }
+        if constexpr (GP < 4) stage_write(vst, (2 + NPAR) * kTileBytes, IntC<GP>{});
+        if constexpr (GP >= 4 && GP < 8) stage_load(vst, vtb, voff, IntC<GP - 4>{});
         if constexpr (GP == 26) load_v4(va, (2 + PAR) * kTileBytes);
         finish_fill(S[PAR], P[PAR], g_c);
       });
@@ -1632,22 +1635,20 @@ void prefill_w64_kernel(const PrefillParams p) {
       load_v4(vb, (2 + PAR) * kTileBytes + 4096);
       pv_phase(P[PAR], IntC<2 + PAR>{}, va, vb, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
-        if constexpr (GP >= 3 && GP < 7) { if (w2) stage_write(kst, PAR * kTileBytes, IntC<GP - 3>{}); }
-        if constexpr (GP == 7) { if (w3) clamp_offsets(i + 3); }
-        if constexpr (GP >= 7 && GP < 11) { if (w3) stage_load(kst, ktb, koff, IntC<GP - 7>{}); }
+        if constexpr (GP >= 3 && GP < 7) stage_write(kst, PAR * kTileBytes, IntC<GP - 3>{});
+        if constexpr (GP == 7) clamp_offsets(min(i + 3, ntiles - 1));
+        if constexpr (GP >= 7 && GP < 11) stage_load(kst, ktb, koff, IntC<GP - 7>{});
         start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c);
       });
       __builtin_amdgcn_sched_barrier(0);
       LV_STAMP(5)
       apply_pending();
     } else {
-      if (w1) static_for<0, 4>([&](auto i_c) { stage_write(vst, (2 + NPAR) * kTileBytes, i_c); });
-      if (w2) static_for<0, 4>([&](auto i_c) { stage_load(vst, vtb, voff, i_c); });
-      if (w2) static_for<0, 4>([&](auto i_c) { stage_write(kst, PAR * kTileBytes, i_c); });
-      if (w3) {
-        clamp_offsets(i + 3);
-        static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb, koff, i_c); });
-      }
+      static_for<0, 4>([&](auto i_c) { stage_write(vst, (2 + NPAR) * kTileBytes, i_c); });
+      static_for<0, 4>([&](auto i_c) { stage_load(vst, vtb, voff, i_c); });
+      static_for<0, 4>([&](auto i_c) { stage_write(kst, PAR * kTileBytes, i_c); });
+      clamp_offsets(min(i + 3, ntiles - 1));
+      static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb, koff, i_c); });
     }
     LV_STAMP(1)
     __syncthreads();
@@ -1658,15 +1659,16 @@ void prefill_w64_kernel(const PrefillParams p) {
     clamp_offsets(0);
     stage_tile_now(0, p.k, k_row_bytes, koff, 0);
     stage_tile_now(0, p.v, v_row_bytes, voff, 2 * kTileBytes);
-    if (ntiles > 1) {
-      clamp_offsets(1);
-      stage_tile_now(1, p.k, k_row_bytes, koff, kTileBytes);
-      gptr vtb1 = tile_base(1, p.v, v_row_bytes);      // V(1) and K(2) stay in the staging sets
+    {
+      // K(1) into its slot; V(1) and K(2) stay in the staging sets (tile indices clamped as in
+      // the iterations)
+      const int t1 = min(1, ntiles - 1), t2 = min(2, ntiles - 1);
+      clamp_offsets(t1);
+      stage_tile_now(t1, p.k, k_row_bytes, koff, kTileBytes);
+      gptr vtb1 = tile_base(t1, p.v, v_row_bytes);
       static_for<0, 4>([&](auto i_c) { stage_load(vst, vtb1, voff, i_c); });
-    }
-    if (ntiles > 2) {
-      clamp_offsets(2);
-      gptr ktb2 = tile_base(2, p.k, k_row_bytes);
+      clamp_offsets(t2);
+      gptr ktb2 = tile_base(t2, p.k, k_row_bytes);
       static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb2, koff, i_c); });
     }
     __syncthreads();
