@@ -90,16 +90,18 @@ __device__ __forceinline__ float pair32_max(float x) {
   return fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
 }
 
-// ---- RB = 2 structure: registers owned by inline asm.
+// ---- prefill_w64_kernel: registers owned by inline asm.
 // At one wave per SIMD the wave has the whole 512-entry register file, but hipcc, left to place an
 // accumulator that both MFMAs and vector code (the rare rescale) touch, moves it between the two
 // halves of the file around every tile. So the output accumulator and the Q fragments are kept in
 // accumulator registers that only asm statements name, and hipcc never sees them as values:
-//   a[0:63]    O^T of row block 0 (column block dt at a[16 dt : 16 dt + 15])
-//   a[64:127]  O^T of row block 1
-//   a[128:159] Q^T fragments of row block 0 (d-step s at a[128 + 4 s : +3]);  a[160:191] row block 1
-// hipcc's own values must all fit the 256 vector registers (it would use free accumulator
-// registers as spill space): after every edit check the .s for v_accvgpr_* outside ASMSTART/ASMEND.
+//   a[64:127]   O^T of row block 0 (column block dt at a[64 + 16 dt : +15])
+//   a[128:191]  O^T of row block 1
+//   a[192:223]  Q^T fragments of row block 0 (d-step s at a[192 + 4 s : +3]);  a[224:255] row block 1
+// a[0:63] stay hipcc's: under register pressure it homes values there (the staging registers:
+// global loads and LDS stores take accumulator registers directly). Nothing reserves a[64:255]
+// for the asm statements, so after every edit the compiled kernel must be checked: no
+// accumulator register above a63 outside ASMSTART/ASMEND (tests/test_abi_cpu.py does it).
 // hipcc does not know these statements are MFMAs, so the wait states between an MFMA result and a
 // vector instruction reading it, and between a vector write and an MFMA reading it, are placed by
 // hand (s_nop inside or beside the statements).
@@ -163,15 +165,13 @@ __device__ __forceinline__ void acc_scale(float alpha) {
                : "=&v"(t) : "v"(alpha), "n"(R));
 }
 
-// NW = waves per workgroup, RB = 32-row query blocks per wave; the workgroup's query tile is
-// 32*RB*NW rows. RB = 1 runs two waves per SIMD on compiler-allocated registers. RB = 2 (NW = 4)
-// runs one wave per SIMD on the whole 512-register file: every K and V fragment read from LDS
-// feeds two MFMAs, which halves the LDS traffic per FLOP.
+// NW = waves per workgroup, RB = 32-row query blocks per wave (1); the workgroup's query tile is
+// 32*RB*NW rows, two waves per SIMD on compiler-allocated registers.
 // DMA = true stages K/V tiles HBM -> LDS directly (global_load_lds, no VGPRs, no ds_write).
 template <bool PAGED, int NW, int RB, bool DMA>
 __global__ __launch_bounds__(64 * NW, (RB == 2 ? 1 : 2))
 void prefill_attn_kernel(const PrefillParams p) {
-  static_assert(RB == 1 || (RB == 2 && NW == 4), "RB = 2 is the 4-wave, one-wave-per-SIMD structure");
+  static_assert(RB == 1, "one 32-row block per wave (64 rows per wave: prefill_w64_kernel)");
   constexpr int BM = 32 * RB * NW;  // query rows per workgroup
   constexpr int NST = 16 / NW;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 4 * NW;     // tile rows between two chunks of one thread
@@ -226,25 +226,6 @@ void prefill_attn_kernel(const PrefillParams p) {
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(qf[rb][s]));
-
-  if constexpr (RB == 2) {
-    // claim a[0:191] for the asm statements (this also sizes the kernel's accumulator file), then
-    // park the Q^T fragments in a[128:191] and zero the output accumulator a[0:127]
-    asm volatile("" ::: LV_ACC_CLOBBERS_0_63, LV_ACC_CLOBBERS_64_127, LV_ACC_CLOBBERS_128_191);
-    static_for<0, 2>([&](auto rb_c) {
-      static_for<0, 8>([&](auto s_c) {
-        constexpr int RBI = decltype(rb_c)::value, S = decltype(s_c)::value;
-        const u32x4 w = __builtin_bit_cast(u32x4, qf[RBI][S]);
-        const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];   // scalars first: see pair32_max
-        acc_write<128 + 32 * RBI + 4 * S + 0>(__builtin_bit_cast(float, w0));
-        acc_write<128 + 32 * RBI + 4 * S + 1>(__builtin_bit_cast(float, w1));
-        acc_write<128 + 32 * RBI + 4 * S + 2>(__builtin_bit_cast(float, w2));
-        acc_write<128 + 32 * RBI + 4 * S + 3>(__builtin_bit_cast(float, w3));
-      });
-    });
-    static_for<0, 128>([&](auto r_c) { acc_write<decltype(r_c)::value>(0.f); });
-    asm volatile("s_nop 3");   // accumulator writes -> first MFMA reading them
-  }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
@@ -537,156 +518,6 @@ void prefill_attn_kernel(const PrefillParams p) {
     LV_STAMP(6)
   };
 
-  // ---- RB = 2: one 64-key tile for the wave's two 32-row blocks, in four phases of 16 MFMAs.
-  //   P1  S0 = K[0:32] Q^T            (both row blocks; each K fragment feeds two MFMAs)
-  //       row maxima of S0, running-max update (accumulator rescale applied here: every earlier
-  //       P V is complete)
-  //   P2  S1 = K[32:64] Q^T     with  P0 = exp2(S0) issued between the MFMAs, one pair per MFMA
-  //       row maxima of S1; a rescale it asks for is held back until P0 V has been added
-  //   P3  O += V[0:32]^T P0     with  P1 = exp2(S1) between the MFMAs
-  //   P4  O += V[32:64]^T P1
-  // The order inside P2/P3 is the source order: a scheduling barrier closes every MFMA + filler
-  // group, because hipcc cannot see an MFMA in the asm statement and would not interleave by itself.
-  auto mfma_settle = [&](f32x16& a, f32x16& b) {
-    // 16 wait states between the last MFMA writing these registers and a vector read of them
-    asm volatile("s_nop 15" : "+v"(a), "+v"(b));
-  };
-  auto row_max2 = [&](int ks0, int rb, f32x16& sacc) -> float {
-    if (ks0 + 31 > wrow0 + 32 * rb + coff) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = ks0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (key > my_lim[rb]) sacc[r] = -INFINITY;
-      }
-    }
-    float a[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a[j]) : "v"(sacc[3 * j]), "v"(sacc[3 * j + 1]), "v"(sacc[3 * j + 2]));
-    float b0, b1;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(a[3]), "v"(a[4]), "v"(sacc[15]));
-    const float mx = fmaxf(b0, b1);
-    return pair32_max(mx);
-  };
-  // O and l of one row block times alpha; the accumulator's last MFMA must have retired
-  auto rescale2 = [&](auto rb_c, float alpha) {
-    constexpr int RBI = decltype(rb_c)::value;
-    l_run[RBI] *= alpha;
-    asm volatile("s_nop 15");
-    static_for<0, 64>([&](auto r_c) { acc_scale<64 * RBI + decltype(r_c)::value>(alpha); });
-    asm volatile("s_nop 3");
-  };
-  auto new_max2 = [&](int rb, float mx) -> float {
-    const float m_new = fmaxf(m_run[rb], mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m_run[rb] - m_use) * cexp);
-    m_run[rb] = m_new;
-    return alpha;
-  };
-  // two probabilities of one row block: registers R, R+1 of its score tile
-  auto exp_pair = [&](const f32x16& sacc, bf16x8 (&pf)[2], float& ps_a, float& ps_b, float mc, auto r_c) {
-    constexpr int R = decltype(r_c)::value;
-    const float pe0 = __builtin_amdgcn_exp2f(fmaf(sacc[R], cexp, -mc));
-    const float pe1 = __builtin_amdgcn_exp2f(fmaf(sacc[R + 1], cexp, -mc));
-    ps_a += pe0;
-    ps_b += pe1;
-    pf[R >> 3][R & 7] = static_cast<__bf16>(pe0);
-    pf[R >> 3][(R & 7) + 1] = static_cast<__bf16>(pe1);
-  };
-
-  auto compute2 = [&](int tile, auto buf_c) {
-    constexpr int BUF = decltype(buf_c)::value;
-    constexpr int kBufOff = BUF * 2 * kTileBytes;
-    const int kt0 = tile * BN;
-    if (kt0 > wrow0 + 63 + coff) return;   // every row of the wave lies above this tile
-
-    bf16x8 kx[8];
-    bf16x8 va[2][4], vb[2][4];
-    f32x16 s0[2], s1[2];          // [row block] scores of keys 0-31 / 32-63
-    bf16x8 p0[2][2], p1[2][2];    // [row block][16-key step]
-
-    // ---- P1
-    load_ka(kx, kBufOff);
-    static_for<0, 8>([&](auto s_c) {
-      constexpr int S = decltype(s_c)::value;
-      mfma_s<128 + 4 * S, S == 0>(s0[0], kx[S]);
-      mfma_s<160 + 4 * S, S == 0>(s0[1], kx[S]);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    load_ka(kx, kBufOff + 8192);
-    load_va(va, kBufOff);
-    mfma_settle(s0[0], s0[1]);
-    float mc0[2];
-    static_for<0, 2>([&](auto rb_c) {
-      constexpr int RBI = decltype(rb_c)::value;
-      const float mx = row_max2(kt0, RBI, s0[RBI]);
-      if (__builtin_amdgcn_ballot_w64(mx - m_run[RBI] > defer_raw) != 0) rescale2(rb_c, new_max2(RBI, mx));
-      mc0[RBI] = ((m_run[RBI] == -INFINITY) ? 0.f : m_run[RBI]) * cexp;
-    });
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- P2: S1 with P0 = exp2(S0)
-    float psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
-    static_for<0, 8>([&](auto s_c) {
-      constexpr int S = decltype(s_c)::value;
-      mfma_s<128 + 4 * S, S == 0>(s1[0], kx[S]);
-      exp_pair(s0[0], p0[0], psa[0], psb[0], mc0[0], IntC<2 * S>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_s<160 + 4 * S, S == 0>(s1[1], kx[S]);
-      exp_pair(s0[1], p0[1], psa[1], psb[1], mc0[1], IntC<2 * S>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    l_run[0] += psa[0] + psb[0];
-    l_run[1] += psa[1] + psb[1];
-    load_va(vb, kBufOff + 8192);
-    mfma_settle(s1[0], s1[1]);
-    float mc1[2], alpha1[2];
-    bool resc1[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const float mx = row_max2(kt0 + 32, rb, s1[rb]);
-      resc1[rb] = __builtin_amdgcn_ballot_w64(mx - m_run[rb] > defer_raw) != 0;
-      alpha1[rb] = 1.f;
-      if (resc1[rb]) alpha1[rb] = new_max2(rb, mx);
-      mc1[rb] = ((m_run[rb] == -INFINITY) ? 0.f : m_run[rb]) * cexp;
-    }
-    // P0 was written by vector instructions: wait states before an MFMA reads it
-    asm volatile("s_nop 1" : "+v"(p0[0][0]), "+v"(p0[0][1]), "+v"(p0[1][0]), "+v"(p0[1][1]));
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- P3: O += V[0:32]^T P0 with P1 = exp2(S1)
-    psa[0] = psa[1] = psb[0] = psb[1] = 0.f;
-    static_for<0, 8>([&](auto i_c) {
-      constexpr int I = decltype(i_c)::value;   // 16-key step I >> 2, column block I & 3
-      constexpr int KS = I >> 2, DT = I & 3;
-      mfma_o<16 * DT>(va[KS][DT], p0[0][KS]);
-      exp_pair(s1[0], p1[0], psa[0], psb[0], mc1[0], IntC<2 * I>{});
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_o<64 + 16 * DT>(va[KS][DT], p0[1][KS]);
-      exp_pair(s1[1], p1[1], psa[1], psb[1], mc1[1], IntC<2 * I>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // P0 V (formed at the old scale) is in; bring O and l to the new one where S1 asked for it
-    if (resc1[0]) rescale2(IntC<0>{}, alpha1[0]);
-    if (resc1[1]) rescale2(IntC<1>{}, alpha1[1]);
-    l_run[0] += psa[0] + psb[0];
-    l_run[1] += psa[1] + psb[1];
-    asm volatile("s_nop 1" : "+v"(p1[0][0]), "+v"(p1[0][1]), "+v"(p1[1][0]), "+v"(p1[1][1]));
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- P4: O += V[32:64]^T P1
-    static_for<0, 8>([&](auto i_c) {
-      constexpr int I = decltype(i_c)::value;
-      constexpr int KS = I >> 2, DT = I & 3;
-      mfma_o<16 * DT>(vb[KS][DT], p1[0][KS]);
-      mfma_o<64 + 16 * DT>(vb[KS][DT], p1[1][KS]);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto run_tile = [&](int tile, auto buf_c) {
-    if constexpr (RB == 2) compute2(tile, buf_c); else compute(tile, buf_c);
-  };
 
   // ---- main loop, LDS-DMA staging: tile t+1 is copied into the other buffer while tile t is
   // computed; the barrier at the end of the interval (its fence waits for the copies) publishes it.
@@ -698,14 +529,14 @@ void prefill_attn_kernel(const PrefillParams p) {
     for (int tile = 0; tile < ntiles; tile += 2) {
       if (tile + 1 < ntiles) stage_dma(tile + 1, IntC<1>{});
       LV_STAMP(3)
-      run_tile(tile, IntC<0>{});
+      compute(tile, IntC<0>{});
       LV_STAMP(1)
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
         if (tile + 2 < ntiles) stage_dma(tile + 2, IntC<0>{});
         LV_STAMP(3)
-        run_tile(tile + 1, IntC<1>{});
+        compute(tile + 1, IntC<1>{});
         LV_STAMP(1)
         if (!(LV_ABL & 256)) __syncthreads();
         LV_STAMP(0)
@@ -721,7 +552,7 @@ void prefill_attn_kernel(const PrefillParams p) {
       if (ntiles > 1) stage_load(1);
     }
     for (int tile = 0; tile < ntiles; tile += 2) {
-      run_tile(tile, IntC<0>{});
+      compute(tile, IntC<0>{});
       if (tile + 1 < ntiles) stage_write(IntC<1>{});
       LV_STAMP(1)
       // the next loads are issued before the barrier: a wave that gets here early spends its
@@ -731,7 +562,7 @@ void prefill_attn_kernel(const PrefillParams p) {
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
-        run_tile(tile + 1, IntC<1>{});
+        compute(tile + 1, IntC<1>{});
         if (tile + 2 < ntiles) stage_write(IntC<0>{});
         LV_STAMP(1)
         if (tile + 3 < ntiles) stage_load(tile + 3);
@@ -744,17 +575,6 @@ void prefill_attn_kernel(const PrefillParams p) {
   LV_STAMP_FLUSH
 
   // ---- epilogue: normalise and store this lane's rows (d = 32*dt + (r&3) + 8*(r>>2) + 4*h)
-  if constexpr (RB == 2) {
-    asm volatile("s_nop 15");   // last MFMA -> accumulator reads
-    static_for<0, 2>([&](auto rb_c) {
-      static_for<0, 4>([&](auto dt_c) {
-        static_for<0, 16>([&](auto r_c) {
-          constexpr int RBI = decltype(rb_c)::value, DT = decltype(dt_c)::value, R = decltype(r_c)::value;
-          oacc[RBI][DT][R] = acc_read<64 * RBI + 16 * DT + R>();
-        });
-      });
-    });
-  }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
@@ -1619,7 +1439,6 @@ void prefill_w64_kernel(const PrefillParams p) {
     // iteration ago, not for the one requested half an iteration ago).
     gptr vtb = tile_base(min(i + 2, ntiles - 1), p.v, v_row_bytes);
     gptr ktb = tile_base(min(i + 3, ntiles - 1), p.k, k_row_bytes);
-    LV_STAMP(3)
     if (i < nact) {
       LV_STAMP_COUNT
       bf16x8 va[4], vb[4];      // V^T fragments of the first two 16-key steps of V(i)
@@ -1631,7 +1450,6 @@ void prefill_w64_kernel(const PrefillParams p) {
         finish_fill(S[PAR], P[PAR], g_c);
       });
       __builtin_amdgcn_sched_barrier(0);
-      LV_STAMP(4)
       load_v4(vb, (2 + PAR) * kTileBytes + 4096);
       pv_phase(P[PAR], IntC<2 + PAR>{}, va, vb, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
@@ -1641,7 +1459,6 @@ void prefill_w64_kernel(const PrefillParams p) {
         start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c);
       });
       __builtin_amdgcn_sched_barrier(0);
-      LV_STAMP(5)
       apply_pending();
     } else {
       static_for<0, 4>([&](auto i_c) { stage_write(vst, (2 + NPAR) * kTileBytes, i_c); });
@@ -1741,7 +1558,7 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
   // cfg 2: the phase-locked 8-wave kernel (long prompts);
-  // cfg 3: 4 waves x 64 rows, one wave per SIMD, asm-placed MFMAs (opt-in).
+  // cfg 4: 4 waves x 64 rows, one wave per SIMD, asm-owned accumulator registers (opt-in).
   // LV_PREFILL_CFG / LV_PREFILL_DMA override the choice (read on every call: tests switch them).
   const char* env_cfg = getenv("LV_PREFILL_CFG");
   const char* env_dma = getenv("LV_PREFILL_DMA");
@@ -1750,8 +1567,6 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   const int dma = env_dma ? atoi(env_dma) : 0;
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
-  } else if (cfg == 3) {
-    if (p.block_table) launch_cfg<true, 4, 2, false>(p, stream); else launch_cfg<false, 4, 2, false>(p, stream);
   } else if (cfg == 2) {
     if (p.block_table) launch_pp<true>(p, stream); else launch_pp<false>(p, stream);
   } else if (p.block_table) {

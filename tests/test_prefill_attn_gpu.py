@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-2
 
 
-@pytest.fixture(autouse=True, params=["auto", "0", "1", "2", "3", "4"], ids=lambda c: f"cfg-{c}")
+@pytest.fixture(autouse=True, params=["auto", "0", "1", "2", "4"], ids=lambda c: f"cfg-{c}")
 def kernel_config(request, monkeypatch):
     """Every case runs under the library's own choice of kernel and under each forced one:
     0 = 4 waves / 128-row tiles, 1 = 8 waves / 256-row tiles, 2 = the phase-locked 8-wave kernel."""
