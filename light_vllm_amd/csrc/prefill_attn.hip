@@ -1401,7 +1401,10 @@ void prefill_w64_kernel(const PrefillParams p) {
   // Vector work of the PV phase (or of the prologue, stand-alone) for the tile whose scores were
   // just formed: gap 0 settles and masks them, gap 1 takes the row maxima and the running-max
   // decisions, gaps 3..30 the first stage of elements 0..27.
-  constexpr int kSplit = 28;     // elements started in the PV phase; the rest start in the QK phase
+#ifndef LV_W64_SPLIT
+#define LV_W64_SPLIT 28
+#endif
+  constexpr int kSplit = LV_W64_SPLIT;   // elements started in the PV phase (<= 28); the rest start in the QK phase
   auto start_fill = [&](int kt0, f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto g_c) {
     constexpr int GP = decltype(g_c)::value;
     if constexpr (GP == 0) { settle(sc); mask_tile(kt0, sc); }
@@ -1437,8 +1440,8 @@ void prefill_w64_kernel(const PrefillParams p) {
     // any more): the memory operations are then the same in every iteration, with no branch
     // around them, and hipcc can count its vmcnt waits exactly (a wait for the set loaded an
     // iteration ago, not for the one requested half an iteration ago).
-    gptr vtb = tile_base(min(i + 2, ntiles - 1), p.v, v_row_bytes);
-    gptr ktb = tile_base(min(i + 3, ntiles - 1), p.k, k_row_bytes);
+    gptr vtb = tile_base((LV_ABL & 8192) ? 0 : min(i + 2, ntiles - 1), p.v, v_row_bytes);
+    gptr ktb = tile_base((LV_ABL & 8192) ? 0 : min(i + 3, ntiles - 1), p.k, k_row_bytes);
     if (i < nact) {
       LV_STAMP_COUNT
       bf16x8 va[4], vb[4];      // V^T fragments of the first two 16-key steps of V(i)
@@ -1468,7 +1471,7 @@ void prefill_w64_kernel(const PrefillParams p) {
       static_for<0, 4>([&](auto i_c) { stage_load(kst, ktb, koff, i_c); });
     }
     LV_STAMP(1)
-    __syncthreads();
+    if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(0)
   };
 
