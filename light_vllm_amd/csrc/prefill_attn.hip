@@ -80,6 +80,23 @@ constexpr float kDeferLog2 = 6.0f;
 template <int V>
 struct IntC { static constexpr int value = V; };
 
+// One 128-column output row from the lane pair (l, l ^ 32) that holds it: lane half h owns
+// columns 8 j + 4 h .. + 3 of every 8-column group j (w[j], two bf16 per dword). One
+// v_permlane32_swap per dword pairs groups 2k and 2k+1, after which the lower lane holds columns
+// 16 k .. + 7 and the upper lane 16 k + 8 .. + 15 contiguously: 8 stores of 16 bytes per lane
+// instead of 16 of 8 (the store tail of these kernels is bound by store instructions, not bytes).
+// Every lane must call it (the exchange needs both halves); only valid rows store.
+__device__ __forceinline__ void store_row_128(uint16_t* row_base, int h, bool valid, const u32x2 (&w)[16]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(w[2 * k][0], w[2 * k + 1][0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(w[2 * k][1], w[2 * k + 1][1], false, false);
+    u32x4 v;
+    v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
+    if (valid) *reinterpret_cast<u32x4*>(row_base + 8 * h + 16 * k) = v;
+  }
+}
+
 // max of x over the lane pair (l, l ^ 32), on the vector ALU (v_permlane32_swap, no LDS round trip).
 // The two result words are copied to scalars before the bit cast: __builtin_bit_cast applied
 // directly to a vector element (sw[1], w.y) compiles to element 0 with this hipcc.
@@ -580,18 +597,16 @@ void prefill_attn_kernel(const PrefillParams p) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int my_row = wrow0 + 32 * rb + c;
-    if (my_row < Lq && !(LV_ABL & 512)) {
-      uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
+    u32x2 w[16];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          u32x2 w;
-          w[0] = pack_bf16x2(oacc[rb][dt][4 * rg + 0] * inv, oacc[rb][dt][4 * rg + 1] * inv);
-          w[1] = pack_bf16x2(oacc[rb][dt][4 * rg + 2] * inv, oacc[rb][dt][4 * rg + 3] * inv);
-          *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * rg) = w;
-        }
-    }
+      for (int rg = 0; rg < 4; ++rg) {
+        w[4 * dt + rg][0] = pack_bf16x2(oacc[rb][dt][4 * rg + 0] * inv, oacc[rb][dt][4 * rg + 1] * inv);
+        w[4 * dt + rg][1] = pack_bf16x2(oacc[rb][dt][4 * rg + 2] * inv, oacc[rb][dt][4 * rg + 3] * inv);
+      }
+    uint16_t* ob = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim;
+    store_row_128(ob, h, my_row < Lq && !(LV_ABL & 512), w);
   }
 }
 
@@ -1009,17 +1024,17 @@ void prefill_pp_kernel(const PrefillParams p) {
   // ---- epilogue
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  if (my_row < Lq) {
-    uint16_t* op = p.o + static_cast<int64_t>(q_start + my_row) * p.o_stride0 + hq * kHeadDim + 4 * h;
+  {
+    u32x2 w[16];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        u32x2 w;
-        w[0] = pack_bf16x2(oacc[dt][4 * rg + 0] * inv, oacc[dt][4 * rg + 1] * inv);
-        w[1] = pack_bf16x2(oacc[dt][4 * rg + 2] * inv, oacc[dt][4 * rg + 3] * inv);
-        *reinterpret_cast<u32x2*>(op + 32 * dt + 8 * rg) = w;
+        w[4 * dt + rg][0] = pack_bf16x2(oacc[dt][4 * rg + 0] * inv, oacc[dt][4 * rg + 1] * inv);
+        w[4 * dt + rg][1] = pack_bf16x2(oacc[dt][4 * rg + 2] * inv, oacc[dt][4 * rg + 3] * inv);
       }
+    uint16_t* ob = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim;
+    store_row_128(ob, h, my_row < Lq, w);
   }
 }
 
@@ -1518,17 +1533,17 @@ void prefill_w64_kernel(const PrefillParams p) {
     const float l_tot = l_lane + __shfl_xor(l_lane, 32);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int my_row = wrow0 + 32 * RBI + c;
-    uint16_t* op = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim + 4 * h;
+    uint16_t* ob = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim;
+    u32x2 w[16];
     static_for<0, 4>([&](auto dt_c) {
       static_for<0, 4>([&](auto rg_c) {
         constexpr int DT = decltype(dt_c)::value, RG = decltype(rg_c)::value;
         constexpr int R0 = kAccO + 64 * RBI + 16 * DT + 4 * RG;
-        u32x2 w;
-        w[0] = pack_bf16x2(acc_read<R0 + 0>() * inv, acc_read<R0 + 1>() * inv);
-        w[1] = pack_bf16x2(acc_read<R0 + 2>() * inv, acc_read<R0 + 3>() * inv);
-        if (my_row < Lq) *reinterpret_cast<u32x2*>(op + 32 * DT + 8 * RG) = w;
+        w[4 * DT + RG][0] = pack_bf16x2(acc_read<R0 + 0>() * inv, acc_read<R0 + 1>() * inv);
+        w[4 * DT + RG][1] = pack_bf16x2(acc_read<R0 + 2>() * inv, acc_read<R0 + 3>() * inv);
       });
     });
+    store_row_128(ob, h, my_row < Lq, w);
   });
 }
 
