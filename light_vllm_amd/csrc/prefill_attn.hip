@@ -1254,6 +1254,10 @@ void prefill_w64_kernel(const PrefillParams p) {
   float st_t = 0.f, st_pe = 0.f, st_even = 0.f;   // stage registers
   auto stream_step = [&](f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto e_c) {
     constexpr int E = decltype(e_c)::value;       // 0..65 (64, 65 drain the pipeline)
+    // entry pin: the stage registers pass through an asm statement that follows the gap's MFMA
+    // in statement order, so hipcc cannot hoist this gap's vector work above that MFMA (it would
+    // otherwise pair the MFMAs up and leave the second one waiting for the matrix pipe)
+    asm volatile("" : "+v"(st_t), "+v"(st_pe), "+v"(st_even));
     if constexpr (E >= 2) {                       // third stage of element E - 2
       constexpr int E2 = E - 2, RB2 = (E2 >> 4) & 1, R2 = E2 & 15;
       ps[RB2] += st_pe;
