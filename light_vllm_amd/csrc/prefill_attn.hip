@@ -1585,7 +1585,7 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   const char* env_cfg = getenv("LV_PREFILL_CFG");
   const char* env_dma = getenv("LV_PREFILL_DMA");
   const int force = env_cfg ? atoi(env_cfg) : -1;
-  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q >= 1024 ? 1 : 0));
+  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q > 1024 ? 1 : 0));
   const int dma = env_dma ? atoi(env_dma) : 0;
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
