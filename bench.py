@@ -272,9 +272,9 @@ def main():
     if rank == 0 and not args.no_aux:
         # every bench rank has released its GPU memory; the engine starts its own one process per GPU
         port = int(os.environ.get("MASTER_PORT", "29500")) + 17
-        legs = [e2e_leg(n, port, "eager", 170)]
+        legs = [e2e_leg(n, port, "eager", 150)]
         if "error" not in legs[0]:
-            legs.append(e2e_leg(n, port + 1, "graph", 170))
+            legs.append(e2e_leg(n, port + 1, "graph", 120))
         result["e2e"] = {"what": "tools/e2e_bench.py: engine generate(), Qwen3-8B shapes, random weights, "
                                  f"TP={n}, batch 256 x 1024-token prompts, 33 new tokens, greedy",
                          "runs": legs}
