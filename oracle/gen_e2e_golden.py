@@ -51,6 +51,31 @@ def config1_prompts():
     return [torch.randint(0, 151936, (256,), generator=g).tolist() for _ in range(4)]
 
 
+def gqa4_config(layers=4):
+    """Qwen3-8B head geometry (32 query / 8 kv heads of 128: 4 query heads per kv head) on a narrow
+    residual stream, so the reference stack still runs on CPU in seconds."""
+    cfg = qwen3_0p6b_config(layers)
+    cfg.num_attention_heads = 32
+    return cfg
+
+
+def prefix_prompts():
+    """BASELINE config 5 in miniature: prompts that share whole 256-token blocks, submitted
+    together, so BlockManager.allocate hits the prefix cache inside one prefill batch and the
+    attention call takes its block-table (paged-prefix) prefill path. No length is a multiple
+    of 256 (a fully cached prompt has zero query rows in the reference)."""
+    g = torch.Generator().manual_seed(77)
+
+    def rnd(n):
+        return torch.randint(0, 151936, (n,), generator=g).tolist()
+
+    base = rnd(512)
+    return [base + rnd(88),            # 600 tokens: owns both shared blocks
+            base[:256] + rnd(300),     # 556: hits the first block only
+            base + rnd(40),            # 552: hits both
+            rnd(300)]                  # no hit
+
+
 def install_stubs():
     fa = types.ModuleType("flash_attn")
 
@@ -77,6 +102,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "e2e_config1.json"))
+    ap.add_argument("--shape", default="0.6b", choices=["0.6b", "gqa4"])
+    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix"])
     args = ap.parse_args()
 
     install_stubs()
@@ -91,7 +118,7 @@ def main():
     from lightvllm.utils.context import reset_context, set_context
     from light_vllm_amd.utils.loader import load_random
 
-    hf = qwen3_0p6b_config(args.layers)
+    hf = qwen3_0p6b_config(args.layers) if args.shape == "0.6b" else gqa4_config(args.layers)
     torch.set_default_dtype(torch.bfloat16)
     model = Qwen3ForCausalLM(hf)
     torch.set_default_dtype(torch.float32)
@@ -111,7 +138,7 @@ def main():
                           num_kvcache_blocks=num_blocks, kvcache_block_size=block_size)
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=args.steps, ignore_eos=True)
-    prompts = config1_prompts()
+    prompts = config1_prompts() if args.scenario == "config1" else prefix_prompts()
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
     for s in seqs:
@@ -134,10 +161,14 @@ def main():
         return torch.tensor(r["input_ids"], dtype=torch.int64), torch.tensor(r["positions"], dtype=torch.int64)
 
     steps = []
+    cached_at_prefill = [0] * len(seqs)
     t0 = time.time()
     with torch.inference_mode():
         while not sch.is_finished():
             batch, is_prefill = sch.schedule()
+            if is_prefill:
+                for s_ in batch:
+                    cached_at_prefill[index[id(s_)]] = s_.num_cached_tokens
             ids, pos = prepare_prefill(batch) if is_prefill else prepare_decode(batch)
             logits = model.compute_logits(model(ids, pos)).float()
             temps = torch.tensor([s.temperature for s in batch], dtype=torch.float32)
@@ -151,7 +182,12 @@ def main():
             sch.postprocess(batch, toks)
             print(f"step {len(steps)} prefill={is_prefill} tokens={toks} t={time.time() - t0:.1f}s", flush=True)
 
-    out = {"model": "Qwen3-0.6B shapes, random init", "layers": args.layers, "seed": args.seed,
+    out = {"model": "Qwen3-0.6B shapes, random init" if args.shape == "0.6b" else
+                    "Qwen3-8B head geometry (32q/8kv x 128) on hidden 1024, random init",
+           "shape": args.shape, "scenario": args.scenario,
+           "prompts": prompts if args.scenario != "config1" else None,
+           "cached_tokens_at_prefill": [int(x) for x in cached_at_prefill],
+           "layers": args.layers, "seed": args.seed,
            "weights": "light_vllm_amd.utils.loader.random_checkpoint(seed, std=0.02)",
            "prompts_seed": 2026, "prompt_len": 256, "num_prompts": 4, "max_tokens": args.steps,
            "dtype": "bfloat16", "steps": steps,

@@ -25,6 +25,21 @@ def qwen3_0p6b_config(layers=28, dtype=torch.bfloat16):
         attention_bias=False, tie_word_embeddings=True, torch_dtype=dtype)
 
 
+def gqa4_config(layers=4, dtype=torch.bfloat16):
+    """Qwen3-8B head geometry (32 q / 8 kv heads) on the 0.6B residual width."""
+    cfg = qwen3_0p6b_config(layers, dtype)
+    cfg.num_attention_heads = 32
+    return cfg
+
+
+def golden_config(golden, dtype=torch.bfloat16):
+    return gqa4_config(golden["layers"], dtype) if golden.get("shape") == "gqa4" else qwen3_0p6b_config(golden["layers"], dtype)
+
+
+def golden_prompts(golden):
+    return golden.get("prompts") or config1_prompts(golden["prompts_seed"], golden["num_prompts"], golden["prompt_len"])
+
+
 def config1_prompts(seed=2026, n=4, length=256):
     g = torch.Generator().manual_seed(seed)
     return [torch.randint(0, 151936, (length,), generator=g).tolist() for _ in range(n)]
@@ -50,7 +65,7 @@ def replay(golden, runner, scheduler, tie_ulps):
     from light_vllm_amd.sampling_params import SamplingParams
     from light_vllm_amd.utils.context import reset_context
     sp = SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"], ignore_eos=True)
-    prompts = config1_prompts(golden["prompts_seed"], golden["num_prompts"], golden["prompt_len"])
+    prompts = golden_prompts(golden)
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
     for s in seqs:
@@ -60,6 +75,9 @@ def replay(golden, runner, scheduler, tie_ulps):
         batch, is_prefill = scheduler.schedule()
         assert is_prefill == rec["prefill"], f"step {step_no}: phase differs"
         assert [index[id(s)] for s in batch] == rec["seqs"], f"step {step_no}: batch differs"
+        if is_prefill and golden.get("cached_tokens_at_prefill"):   # prefix-cache hits as the reference's
+            for s in batch:
+                assert s.num_cached_tokens == golden["cached_tokens_at_prefill"][index[id(s)]]
         ids, pos = runner.prepare_prefill(batch) if is_prefill else runner.prepare_decode(batch)
         logits = runner.run_model(ids, pos, is_prefill).float()
         reset_context()

@@ -42,3 +42,22 @@ def test_generate_api_cpu():
         llm.exit()
     assert [o["token_ids"] for o in outs] == golden["completions"]
     assert llm.last_stats["decode_tokens"] == 4 * (golden["max_tokens"] - 1)
+
+
+def test_prefix_cache_scenario_matches_reference_stack():
+    """Prompts sharing whole blocks, submitted together (BASELINE config 5 in miniature, 32 q / 8
+    kv heads): prefix-cache hits inside one prefill batch, paged-prefix prefill, then decode."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from tests._e2e import golden_config
+    golden = load_golden("e2e_prefix_gqa4.json")
+    assert golden["cached_tokens_at_prefill"] == [0, 256, 512, 0]
+    with cpu_kernels():
+        cfg = Config(None, hf_config=golden_config(golden), device="cpu", num_kvcache_blocks=16,
+                     max_model_len=1024, max_num_batched_tokens=4096, random_seed=golden["seed"])
+        runner = ModelRunner(cfg, 0, [])
+        compared, soft, hard, _ = replay(golden, runner, Scheduler(cfg), tie_ulps=2)
+    assert compared == 4 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert len(soft) <= 2, f"too many tie flips: {soft}"

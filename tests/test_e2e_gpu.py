@@ -86,3 +86,27 @@ def test_generate_free_running(gpu):
         print(f"seq {s}: agrees for {agree}/{len(want)} tokens (first reference near-tie at step {first_tie[s]})")
         assert agree >= first_tie[s]
     assert stats["decode_tokens"] == 4 * (golden["max_tokens"] - 1)
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
+def test_prefix_cache_scenario_gqa4(gpu, enforce_eager):
+    """BASELINE config 5 in miniature on Qwen3-8B head geometry (32 q / 8 kv heads: the matrix-core
+    decode kernel): four prompts sharing whole 256-token blocks, submitted together, so the prefix
+    cache hits inside one prefill batch (cached tokens [0, 256, 512, 0], as the reference's
+    BlockManager decides) and the attention call takes the paged-prefix prefill path, then 23
+    decode steps; teacher-forced and tie-aware against the reference stack's run."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from tests._e2e import golden_config
+    golden = load_golden("e2e_prefix_gqa4.json")
+    cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=64, max_num_seqs=16,
+                 enforce_eager=enforce_eager, random_seed=golden["seed"])
+    runner = ModelRunner(cfg, 0, [])
+    compared, soft, hard, max_dev = replay(golden, runner, Scheduler(cfg), tie_ulps=TIE_ULPS)
+    print(f"compared {compared} tokens, max top-5 logit deviation {max_dev:.4f}, tie flips {soft}, hard mismatches {hard}")
+    runner.exit()
+    assert compared == 4 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert max_dev <= MAX_LOGIT_DEV, f"logit deviation {max_dev}"
+    assert len(soft) <= compared // 10, f"too many tie flips: {soft}"
