@@ -1166,10 +1166,12 @@ void prefill_w64_kernel(const PrefillParams p) {
   u32x4 kst[4], vst[4];
   auto stage_load = [&](u32x4 (&st)[4], gptr tb, const uint32_t (&off)[4], auto i_c) {
     constexpr int I = decltype(i_c)::value;
+    if (LV_ABL & 8) return;
     st[I] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(tb + off[I]);
   };
   auto stage_write = [&](const u32x4 (&st)[4], int slot_off, auto i_c) {
     constexpr int I = decltype(i_c)::value;
+    if (LV_ABL & 16) return;
     *reinterpret_cast<u32x4*>(lds + slot_off + 1024 * NW * I + 1024 * wave + 16 * lane) = st[I];
   };
   // The tile that runs past the sequence end is the last one the workgroup loads: from then on
@@ -1216,8 +1218,10 @@ void prefill_w64_kernel(const PrefillParams p) {
   auto load_k4 = [&](bf16x8 (&kf)[4], int byte_off, auto s0_c) {
     constexpr int S0 = decltype(s0_c)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (LV_ABL & 32) { asm volatile("" : "=v"(kf[j])); continue; }
       kf[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kaddr[S0 + j] + byte_off);
+    }
   };
   // V^T fragments of one 16-key step (four 32-column blocks)
   auto load_v4 = [&](bf16x8 (&vf)[4], int byte_off) {
@@ -1225,6 +1229,7 @@ void prefill_w64_kernel(const PrefillParams p) {
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int second = 0; second < 2; ++second) {
+        if (LV_ABL & 64) { if (second == 0) asm volatile("" : "=v"(vf[dt])); continue; }
         const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
             reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(vaddr[dt][second] + byte_off));
         vf[dt][4 * second + 0] = t[0];
@@ -1368,11 +1373,15 @@ void prefill_w64_kernel(const PrefillParams p) {
   };
 
   // QK phase: scores of the tile in K slot KS into sc; vector work for gap g from fill(IntC<g>)
-  auto qk_phase = [&](f32x16 (&sc)[2][2], auto kslot_c, auto&& fill) {
+  auto qk_phase = [&](f32x16 (&sc)[2][2], auto kslot_c, auto&& pre, auto&& fill) {
     constexpr int KOFF = decltype(kslot_c)::value * kTileBytes;
     bf16x8 ka[4], kb[4];
     load_k4(ka, KOFF, IntC<0>{});
     load_k4(kb, KOFF, IntC<4>{});
+    // the K tile became visible at the barrier just passed, so these reads cannot be issued any
+    // earlier: vector work that does not need them runs under their latency
+    pre();
+    __builtin_amdgcn_sched_barrier(0);
     static_for<0, 2>([&](auto half_c) {
       constexpr int HALF = decltype(half_c)::value;
       static_for<0, 8>([&](auto s_c) {
@@ -1430,18 +1439,16 @@ void prefill_w64_kernel(const PrefillParams p) {
     if constexpr (GP == 1) decide_both(sc);
     if constexpr (GP >= 3 && GP < 3 + kSplit) stream_step(sc, pw, IntC<GP - 3>{});
   };
-  // Vector work of the QK phase: elements kSplit..63 of the previous tile's scores (two per gap
-  // until the 32 gaps suffice), then the two steps that drain the pipeline.
+  // Vector work of the QK phase: elements kSplit..63 of the previous tile's scores: the first
+  // kLeft - 32 under the latency of the phase's first K reads (finish_pre), then one per gap, then
+  // the two steps that drain the pipeline.
+  constexpr int kPre = 64 - kSplit - 32;
+  auto finish_pre = [&](f32x16 (&sc)[2][2], u32 (&pw)[2][2][8]) {
+    static_for<0, kPre>([&](auto j_c) { stream_step(sc, pw, IntC<kSplit + decltype(j_c)::value>{}); });
+  };
   auto finish_fill = [&](f32x16 (&sc)[2][2], u32 (&pw)[2][2][8], auto g_c) {
     constexpr int GP = decltype(g_c)::value;
-    constexpr int kLeft = 64 - kSplit;            // 36
-    constexpr int kDouble = kLeft - 32;           // gaps that take two steps
-    if constexpr (GP < kDouble) {
-      stream_step(sc, pw, IntC<kSplit + 2 * GP>{});
-      stream_step(sc, pw, IntC<kSplit + 2 * GP + 1>{});
-    } else {
-      stream_step(sc, pw, IntC<kSplit + kDouble + GP>{});
-    }
+    stream_step(sc, pw, IntC<kSplit + kPre + GP>{});
     if constexpr (GP == 31) {
       stream_step(sc, pw, IntC<64>{});
       stream_step(sc, pw, IntC<65>{});
@@ -1464,10 +1471,13 @@ void prefill_w64_kernel(const PrefillParams p) {
     if (i < nact) {
       LV_STAMP_COUNT
       bf16x8 va[4], vb[4];      // V^T fragments of the first two 16-key steps of V(i)
-      qk_phase(S[NPAR], IntC<NPAR>{}, [&](auto g_c) {
+      qk_phase(S[NPAR], IntC<NPAR>{}, [&]() { finish_pre(S[PAR], P[PAR]); }, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
-        if constexpr (GP < 4) stage_write(vst, (2 + NPAR) * kTileBytes, IntC<GP>{});
-        if constexpr (GP >= 4 && GP < 8) stage_load(vst, vtb, voff, IntC<GP - 4>{});
+        // staging traffic sits in the middle of the phase, away from the latency-critical reads
+        // at its start (LDS stores are slow, ~13 cycles of the store path each, and reads queue
+        // behind them)
+        if constexpr (GP >= 10 && GP < 14) stage_write(vst, (2 + NPAR) * kTileBytes, IntC<GP - 10>{});
+        if constexpr (GP >= 14 && GP < 18) stage_load(vst, vtb, voff, IntC<GP - 14>{});
         if constexpr (GP == 26) load_v4(va, (2 + PAR) * kTileBytes);
         finish_fill(S[PAR], P[PAR], g_c);
       });
@@ -1475,9 +1485,9 @@ void prefill_w64_kernel(const PrefillParams p) {
       load_v4(vb, (2 + PAR) * kTileBytes + 4096);
       pv_phase(P[PAR], IntC<2 + PAR>{}, va, vb, [&](auto g_c) {
         constexpr int GP = decltype(g_c)::value;
-        if constexpr (GP >= 3 && GP < 7) stage_write(kst, PAR * kTileBytes, IntC<GP - 3>{});
-        if constexpr (GP == 7) clamp_offsets(min(i + 3, ntiles - 1));
-        if constexpr (GP >= 7 && GP < 11) stage_load(kst, ktb, koff, IntC<GP - 7>{});
+        if constexpr (GP >= 18 && GP < 22) stage_write(kst, PAR * kTileBytes, IntC<GP - 18>{});
+        if constexpr (GP == 22) clamp_offsets(min(i + 3, ntiles - 1));
+        if constexpr (GP >= 22 && GP < 26) stage_load(kst, ktb, koff, IntC<GP - 22>{});
         start_fill((i + 1) * BN, S[NPAR], P[NPAR], g_c);
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -1512,7 +1522,7 @@ void prefill_w64_kernel(const PrefillParams p) {
     }
     __syncthreads();
     if (nact > 0) {
-      qk_phase(S[0], IntC<0>{}, [&](auto) {});
+      qk_phase(S[0], IntC<0>{}, [&]() {}, [&](auto) {});
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, 32>([&](auto g_c) {
         start_fill(0, S[0], P[0], g_c);

@@ -107,6 +107,13 @@ def main():
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_g8":
         rows.append(decode_case(256, 1024, 64, 8))
+    if args.what == "decode_ragged":
+        for (Hq, Hkv) in [(32, 8), (16, 8)]:
+            for ns in (1, 2, 4, 8):
+                rows.append(decode_case(256, 1024, Hq, Hkv, nsplit=ns, ragged=True, ordered=True))
+            rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=1, ragged=True, ordered=True))
+            rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=4, ragged=True, ordered=True))
+            rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=16, ragged=True, ordered=True))
     if args.what == "decode_small":
         rows.append(decode_case(1, 32768, 4, 1))
         rows.append(decode_case(8, 32768, 16, 4))

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 #include "../light_vllm_amd/csrc/prefill_attn.hip"  // defines LV_ABL (0 unless -DLV_ABL=n)
@@ -55,13 +56,16 @@ int main(int argc, char** argv) {
   p.batch = B; p.max_seqlen_q = L; p.num_heads = Hq; p.num_kv_heads = Hkv;
   p.scale_log2e = 0.08838834764f * 1.4426950408889634f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int it = 0; it < 3; ++it) {
+  std::vector<float> times;
+  for (int it = 0; it < 30; ++it) {
     CK(hipEventRecord(e0));
     if (lv::launch_prefill_attn(p, nullptr) != 0) return 1;
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("run %d: %.3f ms (diagnostic build LV_ABL=%d)\n", it, ms, LV_ABL);
+    times.push_back(ms);
   }
+  std::sort(times.begin(), times.end());
+  printf("30 launches: min %.3f ms, median %.3f ms (diagnostic build LV_ABL=%d)\n", times[0], times[15], LV_ABL);
 #ifndef LV_STAMPS
   return 0;
 #endif
