@@ -1131,7 +1131,6 @@ void prefill_w64_kernel(const PrefillParams p) {
   const int lrow = lane >> 4;
   const int lchunk = (lane & 15) ^ ((lrow << 2) | (wave & 3));   // swizzle on the source side
   const uint32_t colb = static_cast<uint32_t>(kvh * kHeadDim + 8 * lchunk) * 2u;
-  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds3));
   // per-lane byte offset of this lane's 16 bytes inside a tile, for each of the wave's 4 pieces
   uint32_t koff[4], voff[4];
 #pragma unroll
