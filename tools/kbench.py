@@ -114,6 +114,10 @@ def main():
             rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=1, ragged=True, ordered=True))
             rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=4, ragged=True, ordered=True))
             rows.append(decode_case(256, 4096, Hq, Hkv, nsplit=16, ragged=True, ordered=True))
+    if args.what == "decode_ctx":
+        for ctx in (128, 256, 512, 1024, 2048):
+            rows.append(decode_case(256, ctx, 32, 8))
+            rows.append(decode_case(256, ctx, 16, 8))
     if args.what == "decode_small":
         rows.append(decode_case(1, 32768, 4, 1))
         rows.append(decode_case(8, 32768, 16, 4))
