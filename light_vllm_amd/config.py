@@ -30,10 +30,14 @@ class Config:
     random_seed: Optional[int] = None  # random-init weights (seeded) instead of loading `model`
     random_on_device: bool = False    # benchmarks: draw the random weights on the GPU (fast, not portable)
     dist_init_method: str = "tcp://127.0.0.1:2333"
+    dist_backend: Optional[str] = None  # None: "nccl" (RCCL) on GPUs, "gloo" on CPU
+    shared_device: bool = False       # every rank on cuda:0 with a "gloo" group: rehearses the TP path on one GPU (eager only)
 
     def __post_init__(self):
         assert self.kvcache_block_size % 256 == 0, "kvcache_block_size must be a multiple of 256"
         assert 1 <= self.tensor_parallel_size <= 8
+        if self.shared_device:
+            assert self.enforce_eager and self.dist_backend == "gloo", "shared_device needs enforce_eager and dist_backend='gloo'"
         if self.hf_config is None:
             assert self.model is not None and os.path.isdir(self.model), f"'{self.model}' is not a model directory"
             from transformers import AutoConfig

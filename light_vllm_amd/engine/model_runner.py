@@ -49,14 +49,14 @@ class ModelRunner:
         self.on_gpu = config.device != "cpu"
 
         if self.on_gpu:
-            self.device = torch.device(f"cuda:{rank}")
+            self.device = torch.device(f"cuda:{0 if config.shared_device else rank}")
             torch.cuda.set_device(self.device)
         else:
             self.device = torch.device("cpu")
         self._own_group = False
         if self.world_size > 1 and not dist.is_initialized():
-            backend = "nccl" if self.on_gpu else "gloo"   # "nccl" is RCCL on ROCm
-            kwargs = {"device_id": self.device} if self.on_gpu else {}
+            backend = config.dist_backend or ("nccl" if self.on_gpu else "gloo")   # "nccl" is RCCL on ROCm
+            kwargs = {"device_id": self.device} if backend == "nccl" else {}
             dist.init_process_group(backend, config.dist_init_method, world_size=self.world_size,
                                     rank=rank, **kwargs)
             self._own_group = True

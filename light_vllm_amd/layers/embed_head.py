@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.context import get_context
+from . import tp
 from .tp import tp_rank, tp_size
 
 
@@ -43,7 +44,7 @@ class VocabParallelEmbedding(nn.Module):
         y = F.embedding(x, self.weight)
         if self.tp_size > 1:
             y = y * mask.unsqueeze(-1)
-            dist.all_reduce(y)
+            tp.all_reduce(y)
         return y
 
 
@@ -64,7 +65,6 @@ class ParallelLMHead(VocabParallelEmbedding):
             x = x[last_indices].contiguous()
         logits = F.linear(x, self.weight, self.bias)
         if self.tp_size > 1:
-            parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-            dist.gather(logits, parts, 0)
+            parts = tp.gather_to_rank0(logits)
             logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
         return logits

@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
+from . import tp
 from .tp import divide, tp_rank, tp_size
 
 
@@ -126,7 +127,7 @@ class RowParallelLinear(LinearBase):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = F.linear(x, self.weight)
         if self.tp_size > 1:
-            dist.all_reduce(y)
+            tp.all_reduce(y)
         if self.bias is not None:
             y = y + self.bias
         return y

@@ -3,6 +3,7 @@
 every layer behaves as tp_size 1."""
 from __future__ import annotations
 
+import torch
 import torch.distributed as dist
 
 
@@ -12,6 +13,38 @@ def tp_rank() -> int:
 
 def tp_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _staged(t) -> bool:
+    """True when the collective has to go through host memory: a GPU tensor on a "gloo" group,
+    the single-GPU rehearsal of the tensor-parallel path (Config.shared_device). Never taken
+    with the "nccl" backend."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce(t):
+    """In-place sum over the TP group (reference: layers/linear.py:388-389)."""
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
+def gather_to_rank0(t):
+    """Rank 0 receives every rank's tensor (list in rank order), the others None
+    (reference: layers/embed_head.py:180-192)."""
+    rank0 = tp_rank() == 0
+    if _staged(t):
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(tp_size())] if rank0 else None
+        dist.gather(h, parts, 0)
+        return [p.to(t.device) for p in parts] if rank0 else None
+    parts = [torch.empty_like(t) for _ in range(tp_size())] if rank0 else None
+    dist.gather(t, parts, 0)
+    return parts
 
 
 def divide(numerator: int, denominator: int) -> int:

@@ -1,0 +1,84 @@
+"""Tensor-parallel engine path through the HIP kernels, rehearsed on ONE GPU: two rank processes
+share cuda:0 and exchange through a "gloo" group staged over host memory (Config.shared_device).
+Everything but the collective transport is the production TP=2 path: per-rank head sharding
+(32/8 -> 16/4 q/kv heads, the matrix-core decode kernel), per-rank KV caches with global block
+ids, the shared-memory step RPC, the masked embedding all-reduce and the logits gather
+(reference: engine/model_runner.py:116-180, layers/linear.py:240-395, layers/embed_head.py:18-197).
+
+The run is the prefix-cache scenario recorded from the reference stack at TP=1
+(tests/golden/e2e_prefix_gqa4.json), teacher-forced; the all-reduce changes the bf16 summation
+order, so the comparison is tie-aware as in tests/test_e2e_gpu.py."""
+import json
+import os
+import socket
+
+import pytest
+import torch
+
+from tests._e2e import golden_config, golden_prompts, is_tie, load_golden
+
+pytestmark = pytest.mark.gpu
+TIE_ULPS = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, event, out_path):
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from light_vllm_amd.engine.sequence import Sequence
+    from light_vllm_amd.sampling_params import SamplingParams
+    golden = load_golden("e2e_prefix_gqa4.json")
+    cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=64, max_num_seqs=16,
+                 enforce_eager=True, random_seed=golden["seed"], tensor_parallel_size=world,
+                 dist_backend="gloo", shared_device=True, dist_init_method=f"tcp://127.0.0.1:{port}")
+    if rank != 0:
+        ModelRunner(cfg, rank, event)          # serves the step RPC until "exit"
+        return
+    runner = ModelRunner(cfg, 0, [event])
+    sch = Scheduler(cfg)
+    sp = SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"], ignore_eos=True)
+    seqs = [Sequence(p, sp) for p in golden_prompts(golden)]
+    index = {id(s): i for i, s in enumerate(seqs)}
+    for s in seqs:
+        sch.add(s)
+    compared, soft, hard = 0, [], []
+    for step_no, rec in enumerate(golden["steps"]):
+        batch, is_prefill = sch.schedule()
+        assert is_prefill == rec["prefill"] and [index[id(s)] for s in batch] == rec["seqs"]
+        ours = runner.call("run", batch, is_prefill)
+        for j, (a, b) in enumerate(zip(ours, rec["tokens"])):
+            compared += 1
+            if a != b:
+                (soft if is_tie(rec, j, TIE_ULPS) and a in rec["top5"][j] else hard).append((step_no, rec["seqs"][j], a, b))
+        sch.postprocess(batch, rec["tokens"])
+    runner.call("exit")
+    with open(out_path, "w") as f:
+        json.dump({"compared": compared, "soft": soft, "hard": hard}, f)
+
+
+def test_tp2_shared_gpu_prefix_scenario(gpu, tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    event = ctx.Event()
+    port = _free_port()
+    out_path = os.path.join(str(tmp_path), "tp2.json")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, event, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    res = json.load(open(out_path))
+    golden = load_golden("e2e_prefix_gqa4.json")
+    print(res)
+    assert res["compared"] == 4 * golden["max_tokens"]
+    assert not res["hard"], f"token mismatches outside ties: {res['hard']}"
+    assert len(res["soft"]) <= res["compared"] // 10
