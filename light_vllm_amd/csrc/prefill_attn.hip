@@ -921,17 +921,22 @@ void prefill_pp_kernel(const PrefillParams p) {
       for (int r = 0; r < 16; ++r) seedv[r] = seed;
       float ps4[4] = {0.f, 0.f, 0.f, 0.f};
       qk4(kx[0], IntC<0>{}, seedv, S[NPAR][0]);
-      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<2>{});
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<0>{});
       if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
       __builtin_amdgcn_sched_barrier(0);
       qk4(kx[1], IntC<4>{}, S[NPAR][0], S[NPAR][0]);
-      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<3>{});
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<1>{});
       if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
       __builtin_amdgcn_sched_barrier(0);
       qk4(kx[2], IntC<0>{}, seedv, S[NPAR][1]);
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<2>{});
+      if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
       qk4(kx[3], IntC<4>{}, S[NPAR][1], S[NPAR][1]);
+      if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<3>{});
+      if constexpr (CUR) mix4(IntC<2>{}, IntC<1>{});
       if constexpr (CUR) {
-        l_run += ps4[2] + ps4[3];
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         asm volatile("" ::"v"(l_run), "v"(P[PAR][1][0]), "v"(P[PAR][1][1]));
       }
     }
@@ -962,8 +967,10 @@ void prefill_pp_kernel(const PrefillParams p) {
     if (!(LV_ABL & 256)) __syncthreads();
     LV_STAMP(6)
     __builtin_amdgcn_sched_barrier(0);
-    // ---- C_PV(i): O += V(i)^T P(i); in the MFMAs' shadow the whole softmax of tile i+1:
-    // slice 0 the row maximum and running-max update, slices 1-3 the exponentials
+    // ---- C_PV(i): O += V(i)^T P(i); in the MFMAs' shadow the first half of the softmax of tile
+    // i+1: slice 0 the row maximum and running-max update, slices 1-2 the exponentials of keys
+    // 0-31 (those of keys 32-63 run beside C_QK(i+1): 16 per matrix cluster either way; 12/20 and
+    // 24/8 splits both measured slower)
     __builtin_amdgcn_s_setprio(0);
     {
       float ps4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -985,11 +992,8 @@ void prefill_pp_kernel(const PrefillParams p) {
       if constexpr (CUR) mix4(IntC<3>{}, IntC<2>{});
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (CUR) pv4(vx[0], P[PAR], IntC<3>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps4, IntC<0>{});
-      tail_q(S[NPAR][1], P[NPAR][1], ps4, IntC<1>{});
       l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-      asm volatile("" ::"v"(l_run), "v"(P[NPAR][1][0]));
-      if constexpr (CUR) mix4(IntC<4>{}, IntC<2>{});
+      asm volatile("" ::"v"(l_run));
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(3)
