@@ -906,6 +906,15 @@ void prefill_pp_kernel(const PrefillParams p) {
         pend = false;
       }
     }
+    // one splat of -m feeds the first MFMA of both 32-key halves as its C operand; formed here,
+    // where the wave would otherwise only wait at the barrier, not at the head of the matrix cluster
+    f32x16 seedv;
+    {
+      const float seed = (m_run == -INFINITY) ? 0.f : -m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) seedv[r] = seed;
+      asm volatile("" : "+v"(seedv));
+    }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(0)
     if (!(LV_ABL & 256)) __syncthreads();
@@ -914,11 +923,6 @@ void prefill_pp_kernel(const PrefillParams p) {
     // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
     __builtin_amdgcn_s_setprio(0);
     {
-      // one splat of -m feeds the first MFMA of both 32-key halves as its C operand
-      const float seed = (m_run == -INFINITY) ? 0.f : -m_run;
-      f32x16 seedv;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) seedv[r] = seed;
       float ps4[4] = {0.f, 0.f, 0.f, 0.f};
       qk4(kx[0], IntC<0>{}, seedv, S[NPAR][0]);
       if constexpr (CUR) tail_q(S[PAR][1], P[PAR][1], ps4, IntC<0>{});
