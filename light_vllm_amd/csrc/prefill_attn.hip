@@ -737,6 +737,7 @@ void prefill_pp_kernel(const PrefillParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  float defer_thr = -INFINITY;
   float pend_alpha = 1.f;
   bool pend = false;
 
@@ -830,12 +831,22 @@ void prefill_pp_kernel(const PrefillParams p) {
     const float b1 = max3(a[3], a[4], a[5]);
     const float b2 = max3(a[6], a[7], a[8]);
     const float b3 = max3(a[9], sa[15], sb[15]);
-    float mx = fmaxf(max3(b0, b1, b2), b3);
+    // plain v_max_f32 / v_max3_f32 on these values: fmaxf adds a canonicalising v_max per operand
+    // to a chain that every exponential of the tile waits for
+    float mx = max3(max3(b0, b1, b2), b3, b3);
     if (LV_ABL & 1024) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
-    mx = pair32_max(mx);
+    {
+      const unsigned xb = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      const unsigned lo = sw[0], hi = sw[1];
+      const float flo = __builtin_bit_cast(float, lo), fhi = __builtin_bit_cast(float, hi);
+      mx = max3(flo, fhi, fhi);
+    }
     if (LV_ABL & 2048) { asm volatile("" ::"v"(mx)); m_run = 0.f; return; }
-    const bool fresh = m_run == -INFINITY;
-    if (__builtin_amdgcn_ballot_w64(fresh || mx > kDeferLog2) != 0) {
+    // defer_thr is the deferral threshold for a row that has a maximum and -inf for one that has
+    // none yet (any finite score then moves it): one compare decides both cases
+    if (__builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {
+      const bool fresh = m_run == -INFINITY;
       const float m_off = fresh ? 0.f : m_run;
       const float m_new = fmaxf(m_run, m_off + mx);
       const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_off;
@@ -844,6 +855,7 @@ void prefill_pp_kernel(const PrefillParams p) {
       for (int r = 0; r < 16; ++r) { sa[r] -= delta; sb[r] -= delta; }
       l_run *= alpha;
       m_run = m_new;
+      defer_thr = (m_new == -INFINITY) ? -INFINITY : kDeferLog2;
       pend_alpha = alpha;
       pend = true;
     }
