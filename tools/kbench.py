@@ -39,7 +39,7 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
     q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
     bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
     if ragged:
-        lens = torch.randint(1, ctx + 1, (B,), dtype=torch.int32)
+        lens = torch.randint(1, ctx + 1, (B,), dtype=torch.int32, generator=torch.Generator().manual_seed(0))
     else:
         lens = torch.full((B,), ctx, dtype=torch.int32)
     ctx_t = lens.to(dev)
