@@ -194,7 +194,11 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
  *                 pass through `workspace` (>= lv_decode_workspace_bytes bytes, 16-byte aligned).
  *   seq_order     optional int32 [batch] permutation of 0..batch-1 (NULL = identity): the order
  *                 in which sequences are handed to the GPU. Passing the sequences longest first
- *                 evens out the tail of a ragged batch; results do not depend on it. Entries
+ *                 evens out the tail of a ragged batch; results do not depend on it. With an
+ *                 order the kernels also take all kv heads of 32 launch positions before the
+ *                 next 32 (without one: every sequence of one kv head before the next head,
+ *                 which is ~3 % faster when all lengths are equal, so pass NULL for such a
+ *                 batch). Entries
  *                 outside [0, batch) are skipped (that sequence's output is then not written).
  *                 No counterpart in the reference call; a caller that has no lengths on the
  *                 host passes NULL.

@@ -242,7 +242,7 @@ class ModelRunner:
         bs = self.block_size
         input_ids = [seq.last_token for seq in seqs]
         positions = [len(seq) for seq in seqs]
-        context_lens = [len(seq) for seq in seqs]
+        context_lens = context_lens_host = [len(seq) for seq in seqs]
         slot_mapping = [seq.block_table[-1] * bs + seq.last_block_num_tokens - 1 for seq in seqs]
         input_ids = self._to_device(input_ids, torch.int64)
         positions = self._to_device(positions, torch.int64)
@@ -250,9 +250,12 @@ class ModelRunner:
         context_lens = self._to_device(context_lens, torch.int32)
         block_tables = self.prepare_block_tables(seqs)
         # launch order for the decode kernel: longest sequences first (stable), so a ragged batch
-        # does not end on a long straggler; the host already has the lengths
-        order = sorted(range(len(seqs)), key=lambda j: -len(seqs[j]))
-        seq_order = self._to_device(order, torch.int32)
+        # does not end on a long straggler; the host already has the lengths. Batches of nearly
+        # equal lengths are faster in the kernel's default order (no order passed).
+        seq_order = None
+        if max(context_lens_host) - min(context_lens_host) > max(context_lens_host) // 4:
+            order = sorted(range(len(seqs)), key=lambda j: -len(seqs[j]))
+            seq_order = self._to_device(order, torch.int32)
         set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables,
                     seq_order=seq_order)
         return input_ids, positions
@@ -280,7 +283,8 @@ class ModelRunner:
         gv["context_lens"][:bs] = context.context_lens
         gv["block_tables"][:bs, :context.block_tables.size(1)] = context.block_tables
         gv["seq_order"][:bucket] = self._iota[:bucket]     # padding rows keep their own index ...
-        gv["seq_order"][:bs] = context.seq_order           # ... behind the real rows, longest first
+        if context.seq_order is not None:
+            gv["seq_order"][:bs] = context.seq_order       # ... behind the real rows, longest first
         self.graphs[bucket].replay()
         return self.model.compute_logits(gv["outputs"][:bs])
 

