@@ -22,15 +22,29 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxSplits = 512;
 constexpr int kSplitUnitTokens = 64;  // split granularity of the decode kernel
-constexpr int kTargetWorkgroups = 1024;  // 256 CUs x 4 resident 256-thread workgroups
+constexpr int kFillWorkgroups = 256;      // one workgroup per CU
+constexpr int kLongSplitTokens = 1024;    // a split longer than this is cut further ...
+constexpr int kMaxWorkgroups = 2048;      // ... while the launch stays below this many workgroups
+constexpr int kSaturatedUnits = 1024;     // (sequence, kv head) pairs that fill the chip unsplit
 
+// Split count from the launch shape alone (lengths live on the device; `max_blocks_per_seq` is
+// the table capacity). Fitted to a sweep under hipGraph replay over 1-32 sequences, 1-8 kv heads
+// and 1k-32k tokens: the best count puts about one workgroup on every CU, cuts splits that would
+// be longer than ~1024 tokens while the launch has fewer than ~2048 workgroups, and never goes
+// below the kernel's 64-token split unit. (32768 tokens, 1 sequence, 4q/1kv: 512 splits 16.4 us,
+// 256 splits 12.6 us, 8 splits 60 us; 8 sequences, 32q/8kv: 4 splits 240 us, 32 splits 170 us.)
 static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
   if (units <= 0 || max_blocks_per_seq <= 0) return 1;
-  if (units >= kTargetWorkgroups) return 1;
-  int64_t n = (kTargetWorkgroups + units - 1) / units;
-  const int64_t max_units = (static_cast<int64_t>(max_blocks_per_seq) * block_size + kSplitUnitTokens - 1) / kSplitUnitTokens;
-  if (n > max_units) n = max_units;
+  if (units >= kSaturatedUnits) return 1;
+  const int64_t cap_tokens = static_cast<int64_t>(max_blocks_per_seq) * block_size;
+  const int64_t fill = (kFillWorkgroups + units - 1) / units;
+  int64_t cut = (cap_tokens + kLongSplitTokens - 1) / kLongSplitTokens;
+  const int64_t cut_limit = kMaxWorkgroups / units > 1 ? kMaxWorkgroups / units : 1;
+  if (cut > cut_limit) cut = cut_limit;
+  int64_t n = fill > cut ? fill : cut;
+  const int64_t max_n = (cap_tokens + kSplitUnitTokens - 1) / kSplitUnitTokens;
+  if (n > max_n) n = max_n;
   if (n > kMaxSplits) n = kMaxSplits;
   return n < 1 ? 1 : static_cast<int>(n);
 }

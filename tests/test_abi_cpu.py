@@ -40,9 +40,10 @@ def test_host_only_entry_points():
     assert lib.lv_decode_workspace_bytes(4, 32, 128, 8) == 4 * 32 * 8 * 130 * 4
     assert lib.lv_decode_workspace_bytes(4, 32, 64, 8) == 0
     assert lib.lv_decode_num_splits(256, 8, 4, 256) == 1      # enough (sequence, kv head) units already
-    assert lib.lv_decode_num_splits(1, 1, 128, 256) == 512    # one long sequence: 64-token split units
-    assert lib.lv_decode_num_splits(8, 8, 128, 256) == 16
-    assert lib.lv_decode_num_splits(1, 8, 1, 256) == 4        # a single block still splits 4 ways
+    assert lib.lv_decode_num_splits(1, 1, 128, 256) == 256    # one long sequence: a workgroup per CU
+    assert lib.lv_decode_num_splits(8, 8, 128, 256) == 32     # 32k-token capacity: ~1024 tokens per split
+    assert lib.lv_decode_num_splits(1, 8, 1, 256) == 4        # a single block: the kernel's 64-token unit
+    assert lib.lv_decode_num_splits(64, 8, 16, 256) == 4      # long splits are cut while the launch is small
 
 
 def test_argument_validation_happens_before_any_launch():

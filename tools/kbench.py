@@ -29,7 +29,28 @@ def timeit(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False):
+def timeit_graph(fn, iters=20, warmup=3, replays=5):
+    """The same launches captured in one hipGraph and replayed: takes the host's per-call cost
+    (argument checks, ctypes) out of cases whose GPU time is shorter than it."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (iters * replays) * 1e-3
+
+
+def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False, graph=False):
     bps = (ctx + BLOCK - 1) // BLOCK
     nblk = B * bps
     # several distinct caches so the working set exceeds the 256 MiB Infinity Cache
@@ -53,7 +74,9 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
         state["i"] += 1
         ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out, seq_order=order)
 
-    t = timeit(fn)
+    if graph:
+        ops.reserve_decode_workspace(dev, 256 << 20)
+    t = timeit_graph(fn) if graph else timeit(fn)
     tot = int(lens.sum())
     nb = int(((lens + BLOCK - 1) // BLOCK).sum())
     bytes_ = tot * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nb
@@ -118,9 +141,18 @@ def main():
         for ctx in (128, 256, 512, 1024, 2048):
             rows.append(decode_case(256, ctx, 32, 8))
             rows.append(decode_case(256, ctx, 16, 8))
-    if args.what == "decode_small":
-        rows.append(decode_case(1, 32768, 4, 1))
-        rows.append(decode_case(8, 32768, 16, 4))
+    if args.what == "decode_small":      # hipGraph replay: the GPU time of launch-bound shapes
+        for (Hq, Hkv) in [(32, 8), (16, 4), (4, 1)]:
+            for (B, ctx) in [(1, 1024), (8, 1024), (1, 32768), (8, 32768)]:
+                for ns in (0, 1):
+                    rows.append(decode_case(B, ctx, Hq, Hkv, nsplit=ns, graph=True))
+    if args.what == "decode_splits":     # split-count sweep around the heuristic, hipGraph replay
+        for (Hq, Hkv) in [(4, 1), (16, 4), (32, 8)]:
+            for (B, ctx) in [(1, 32768), (8, 32768), (1, 4096), (8, 4096), (32, 4096), (1, 1024), (8, 1024)]:
+                for ns in (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
+                    if ns and (ns > ctx // 64 or ctx // ns > 4096):
+                        continue
+                    rows.append(decode_case(B, ctx, Hq, Hkv, nsplit=ns, graph=True))
     for r in rows:
         print(json.dumps(r), flush=True)
 
