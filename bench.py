@@ -100,14 +100,22 @@ def allreduce_bench(dist, dev, n, iters=20):
     return out
 
 
-def e2e_leg(n, port, mode, limit_s):
-    """tools/e2e_bench.py in a child process group of its own (killed as a group at the limit)."""
+TUNED_GEMMS = os.path.join(ROOT, "tools", "tunable", "tunableop.csv")   # PyTorch appends the device ordinal
+
+
+def e2e_leg(n, port, mode, limit_s, tuned_gemms=False):
+    """tools/e2e_bench.py in a child process group of its own (killed as a group at the limit).
+    tuned_gemms: PyTorch's TunableOp picks the model's GEMM kernels from the committed selection
+    file (read only, no tuning in the run; a file recorded for other library versions is ignored)."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "e2e_bench.py"), "--model", "8b", "--tp", str(n),
            "--batch", "256", "--prompt-len", "1024", "--new-tokens", "33", "--modes", mode,
            "--dist-port", str(port)]
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                         "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    if tuned_gemms:
+        env.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="0",
+                   PYTORCH_TUNABLEOP_FILENAME=TUNED_GEMMS)
     t0 = time.perf_counter()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
                             start_new_session=True)
@@ -125,6 +133,7 @@ def e2e_leg(n, port, mode, limit_s):
             try:
                 rec = json.loads(line)
                 rec["wall_s"] = round(time.perf_counter() - t0, 1)
+                rec["gemm_selection"] = "tunableop file" if tuned_gemms else "library default"
                 return rec
             except ValueError:
                 pass
@@ -275,6 +284,8 @@ def main():
         legs = [e2e_leg(n, port, "eager", 150)]
         if "error" not in legs[0]:
             legs.append(e2e_leg(n, port + 1, "graph", 120))
+            if n == 1 and "error" not in legs[-1] and os.path.exists(TUNED_GEMMS.replace(".csv", "0.csv")):
+                legs.append(e2e_leg(n, port + 2, "graph", 120, tuned_gemms=True))
         result["e2e"] = {"what": "tools/e2e_bench.py: engine generate(), Qwen3-8B shapes, random weights, "
                                  f"TP={n}, batch 256 x 1024-token prompts, 33 new tokens, greedy",
                          "runs": legs}
