@@ -292,7 +292,10 @@ class ModelRunner:
         input_ids, positions = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
         temperatures = self.prepare_sample(seqs) if self.rank == 0 else None
         logits = self.run_model(input_ids, positions, is_prefill)
-        token_ids = self.sampler(logits, temperatures).tolist() if self.rank == 0 else None
+        token_ids = None
+        if self.rank == 0:      # only rank 0's sequences carry their sampling parameters
+            all_greedy = all(seq.temperature == 0 for seq in seqs)
+            token_ids = self.sampler(logits, temperatures, all_greedy).tolist()
         reset_context()
         return token_ids
 
