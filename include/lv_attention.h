@@ -198,7 +198,8 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
  *                 order the kernels also take all kv heads of 32 launch positions before the
  *                 next 32 (without one: every sequence of one kv head before the next head,
  *                 which is ~3 % faster when all lengths are equal, so pass NULL for such a
- *                 batch). Entries
+ *                 batch). A negative FIRST entry makes the call behave as with NULL (a captured
+ *                 hipGraph, whose pointers are fixed, switches per replay this way). Other entries
  *                 outside [0, batch) are skipped (that sequence's output is then not written).
  *                 No counterpart in the reference call; a caller that has no lengths on the
  *                 host passes NULL.

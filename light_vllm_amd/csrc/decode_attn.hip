@@ -47,10 +47,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // Measured, 256 sequences of 1..1024 / 1..4096 tokens: 68 -> 73 % / 73 -> 78 % of HBM peak with
 // 4 query heads per kv head, 73 -> 77 % / 77 -> 81 % with 2; groups of 8 lose it again, and
 // batches of equal lengths run 3 % slower grouped, which is why the order is the switch.
+// A negative first entry stands for "no order" (identity, ungrouped): a captured hipGraph, whose
+// pointer arguments are fixed, can then switch per replay by what it writes into its buffer.
 constexpr int kOrderGroup = 32;
-__device__ __forceinline__ void work_item(const DecodeParams& p, int bk, int& bi, int& kvh) {
-  if (p.seq_order == nullptr) {
-    bi = bk % p.batch;
+__device__ __forceinline__ void work_item(const DecodeParams& p, int bk, int& b, int& kvh) {
+  if (p.seq_order == nullptr || p.seq_order[0] < 0) {
+    b = bk % p.batch;
     kvh = bk / p.batch;
     return;
   }
@@ -58,7 +60,7 @@ __device__ __forceinline__ void work_item(const DecodeParams& p, int bk, int& bi
   const int grp = bk / per_group;
   const int rem = bk - grp * per_group;
   const int size = min(kOrderGroup, p.batch - grp * kOrderGroup);   // the last group may be short
-  bi = grp * kOrderGroup + rem % size;
+  b = p.seq_order[grp * kOrderGroup + rem % size];
   kvh = rem / size;
 }
 
@@ -75,9 +77,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
   const int bid = blockIdx.x;
   const int split = bid % nsplit;
   const int bk = bid / nsplit;
-  int bi, kvh;
-  work_item(p, bk, bi, kvh);
-  const int b = p.seq_order ? p.seq_order[bi] : bi;   // caller-chosen launch order (longest first)
+  int b, kvh;
+  work_item(p, bk, b, kvh);   // caller-chosen launch order (longest first), if any
   if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
 
   const int tid = threadIdx.x;
@@ -324,9 +325,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams 
   const int bid = blockIdx.x;
   const int split = bid % nsplit;
   const int bk = bid / nsplit;
-  int bi, kvh;
-  work_item(p, bk, bi, kvh);
-  const int b = p.seq_order ? p.seq_order[bi] : bi;   // caller-chosen launch order (longest first)
+  int b, kvh;
+  work_item(p, bk, b, kvh);   // caller-chosen launch order (longest first), if any
   if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
 
   const int tid = threadIdx.x;

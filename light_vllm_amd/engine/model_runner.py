@@ -282,9 +282,11 @@ class ModelRunner:
         gv["slot_mapping"][:bs] = context.slot_mapping
         gv["context_lens"][:bs] = context.context_lens
         gv["block_tables"][:bs, :context.block_tables.size(1)] = context.block_tables
-        gv["seq_order"][:bucket] = self._iota[:bucket]     # padding rows keep their own index ...
         if context.seq_order is not None:
-            gv["seq_order"][:bs] = context.seq_order       # ... behind the real rows, longest first
+            gv["seq_order"][:bucket] = self._iota[:bucket]  # padding rows keep their own index ...
+            gv["seq_order"][:bs] = context.seq_order        # ... behind the real rows, longest first
+        else:
+            gv["seq_order"][:1] = -1                        # nearly equal lengths: the kernel's default order
         self.graphs[bucket].replay()
         return self.model.compute_logits(gv["outputs"][:bs])
 

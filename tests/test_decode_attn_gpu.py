@@ -148,6 +148,9 @@ def test_decode_seq_order_does_not_change_results(gpu, Hq, Hkv):
             out = ops.decode_attention(*args, num_splits=ns, seq_order=so)
             ref = base if ns == 0 else ops.decode_attention(*args, num_splits=ns)
             assert torch.equal(out, ref)
+    # a negative first entry = no order at all (how a captured graph switches the order off)
+    so = torch.tensor([-1, 7, 7, 7, 99, -5, 0, 0], dtype=torch.int32, device=gpu)
+    assert torch.equal(ops.decode_attention(*args, num_splits=1, seq_order=so), ops.decode_attention(*args, num_splits=1))
     so = torch.tensor([0, 1, 2, 3, 4, 5, 6, 99], dtype=torch.int32, device=gpu)
     out = torch.full_like(base, 7.0)
     ops.decode_attention(*args, num_splits=1, out=out, seq_order=so)
