@@ -146,6 +146,18 @@ def main():
             for (B, ctx) in [(1, 1024), (8, 1024), (1, 32768), (8, 32768)]:
                 for ns in (0, 1):
                     rows.append(decode_case(B, ctx, Hq, Hkv, nsplit=ns, graph=True))
+    if args.what == "fused":             # elementwise kernels either side of attention, prefill sizes
+        N, E, I, Hq, Hkv = 16384, 4096, 12288, 32, 8
+        x = torch.randn(N, 2 * I, device=dev).to(torch.bfloat16)
+        o = torch.empty(N, I, dtype=torch.bfloat16, device=dev)
+        t = timeit(lambda: ops.silu_and_mul(x, out=o))
+        rows.append(dict(kind="silu_and_mul", N=N, I=I, us=round(t * 1e6, 1), GBs=round(N * I * 6 / t / 1e9, 1)))
+        h = torch.randn(N, E, device=dev).to(torch.bfloat16)
+        r = torch.randn(N, E, device=dev).to(torch.bfloat16)
+        w = torch.randn(E, device=dev).to(torch.bfloat16)
+        t = timeit(lambda: ops.add_rms_norm(h, r, w, 1e-6))
+        rows.append(dict(kind="add_rms_norm", N=N, E=E, us=round(t * 1e6, 1), GBs=round(N * E * 8 / t / 1e9, 1)))
+        del x, o
     if args.what == "decode_splits":     # split-count sweep around the heuristic, hipGraph replay
         for (Hq, Hkv) in [(4, 1), (16, 4), (32, 8)]:
             for (B, ctx) in [(1, 32768), (8, 32768), (1, 4096), (8, 4096), (32, 4096), (1, 1024), (8, 1024)]:
