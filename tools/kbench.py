@@ -158,6 +158,19 @@ def main():
         t = timeit(lambda: ops.add_rms_norm(h, r, w, 1e-6))
         rows.append(dict(kind="add_rms_norm", N=N, E=E, us=round(t * 1e6, 1), GBs=round(N * E * 8 / t / 1e9, 1)))
         del x, o
+        qkv = torch.randn(N, (Hq + 2 * Hkv) * D, device=dev).to(torch.bfloat16)
+        q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+        pos = torch.arange(N, device=dev) % 4096
+        qw = torch.randn(D, device=dev).to(torch.bfloat16)
+        cs = torch.randn(4096, D, device=dev)
+        nblk = N // BLOCK
+        kc = torch.zeros(nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        slots = torch.randperm(N, device=dev).to(torch.int32)
+        t = timeit(lambda: ops.qk_norm_rope_store(q.view(N, Hq, D), k.view(N, Hkv, D), v.view(N, Hkv, D), pos, qw, qw, 1e-6,
+                                                  cs, kc, vc, slots))
+        nbytes = N * D * 2 * (2 * Hq + 2 * Hkv + Hkv + 2 * Hkv)
+        rows.append(dict(kind="qk_norm_rope_store", N=N, Hq=Hq, Hkv=Hkv, us=round(t * 1e6, 1), GBs=round(nbytes / t / 1e9, 1)))
     if args.what == "decode_splits":     # split-count sweep around the heuristic, hipGraph replay
         for (Hq, Hkv) in [(4, 1), (16, 4), (32, 8)]:
             for (B, ctx) in [(1, 32768), (8, 32768), (1, 4096), (8, 4096), (32, 4096), (1, 1024), (8, 1024)]:
