@@ -1,0 +1,82 @@
+"""Randomised shape sweep: the HIP decode and prefill kernels against the CPU fp32 oracle on
+seeded random combinations of batch size, lengths (short, block-boundary and long), head
+grouping, block size, split count, launch order and kernel choice — the corners between the
+hand-picked cases of the other GPU tests. Tolerance as there: max-abs <= 2e-2 on bf16 outputs."""
+import pytest
+import torch
+
+from oracle.attention_oracle import decode_ref, prefill_ref
+from tests._cases import make_decode_case, make_prefill_case, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+GROUPS = [(1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (8, 4), (16, 8), (32, 8), (16, 4), (64, 8)]
+
+
+def _lengths(g, n, hi):
+    """Mix of tiny, block-boundary and arbitrary lengths up to hi."""
+    special = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513]
+    out = []
+    for _ in range(n):
+        if torch.rand((), generator=g).item() < 0.4:
+            out.append(min(special[int(torch.randint(0, len(special), (), generator=g))], hi))
+        else:
+            out.append(int(torch.randint(1, hi + 1, (), generator=g)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_decode(gpu, monkeypatch, seed):
+    from light_vllm_amd import ops
+    g = torch.Generator().manual_seed(1000 + seed)
+    Hq, Hkv = GROUPS[int(torch.randint(0, len(GROUPS), (), generator=g))]
+    block = [32, 64, 128, 256][int(torch.randint(0, 4, (), generator=g))]
+    B = int(torch.randint(1, 41, (), generator=g))
+    lens = _lengths(g, B, 700)
+    if torch.rand((), generator=g).item() < 0.3:
+        lens[int(torch.randint(0, B, (), generator=g))] = 0          # an empty row
+    ns = [0, 1, 2, 3, 5][int(torch.randint(0, 5, (), generator=g))]
+    if Hq // Hkv <= 8 and torch.rand((), generator=g).item() < 0.5:  # either kernel for any group size
+        monkeypatch.setenv("LV_DECODE_MFMA", str(int(torch.randint(0, 2, (), generator=g))))
+    case = make_decode_case(2000 + seed, lens, Hq, Hkv, block_size=block, pad_cols=int(torch.randint(0, 3, (), generator=g)))
+    d = to_dev(case, gpu)
+    order = None
+    if torch.rand((), generator=g).item() < 0.5:
+        order = torch.tensor(sorted(range(B), key=lambda j: -lens[j]), dtype=torch.int32, device=gpu)
+    out = ops.decode_attention(d["q"], d["k_cache"], d["v_cache"], d["context_lens"], d["block_table"], d["scale"],
+                               num_splits=ns, seq_order=order)
+    torch.cuda.synchronize()
+    ref = decode_ref(case["q"], case["k_cache"], case["v_cache"], case["context_lens"], case["block_table"], case["scale"])
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= TOL, f"seed {seed}: Hq/Hkv {Hq}/{Hkv} block {block} B {B} splits {ns}: max-abs {err}"
+    for b, L in enumerate(lens):
+        if L == 0:
+            assert bool((out[b] == 0).all())
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_prefill(gpu, monkeypatch, seed):
+    from light_vllm_amd import ops
+    g = torch.Generator().manual_seed(3000 + seed)
+    Hq, Hkv = [(2, 1), (4, 1), (8, 1), (8, 4), (16, 8), (32, 8), (12, 4), (3, 1)][int(torch.randint(0, 8, (), generator=g))]
+    B = int(torch.randint(1, 6, (), generator=g))
+    lens_q = _lengths(g, B, 600)
+    paged = torch.rand((), generator=g).item() < 0.5
+    block = [64, 128, 256][int(torch.randint(0, 3, (), generator=g))]
+    if paged:   # prefix-cached prefill: the cached part is a whole number of blocks
+        lens_k = [lq + block * int(torch.randint(0, 3, (), generator=g)) for lq in lens_q]
+    else:
+        lens_k = list(lens_q)
+    cfg = ["auto", "0", "1", "2", "4"][int(torch.randint(0, 5, (), generator=g))]
+    if cfg == "auto":
+        monkeypatch.delenv("LV_PREFILL_CFG", raising=False)
+    else:
+        monkeypatch.setenv("LV_PREFILL_CFG", cfg)
+    case = make_prefill_case(4000 + seed, lens_q, lens_k, Hq, Hkv, block_size=block, paged=paged)
+    d = to_dev(case, gpu)
+    out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                                block_table=d["block_table"])
+    torch.cuda.synchronize()
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"], case["block_table"])
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= TOL, f"seed {seed}: Hq/Hkv {Hq}/{Hkv} cfg {cfg} paged {paged} block {block} lens {lens_q}/{lens_k}: max-abs {err}"
