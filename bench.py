@@ -103,6 +103,36 @@ def allreduce_bench(dist, dev, n, iters=20):
 TUNED_GEMMS = os.path.join(ROOT, "tools", "tunable", "tunableop.csv")   # PyTorch appends the device ordinal
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X
+
+
+def prefill_leg(torch, ops, dev, n, iters=10):
+    """Varlen causal prefill attention of the Qwen3-8B prefill configuration (4 x 4096-token
+    prompts, packed) on this rank's TP head share: TFLOP/s of the algorithmic causal FLOP count
+    and the fraction of the dense bf16 matrix peak, timed with events on the launch stream."""
+    Hq, Hkv, L, Bp = max(32 // n, 1), max(8 // n, 1), 4096, 4
+    g = torch.Generator(device=dev).manual_seed(1)
+    q = torch.randn(Bp * L, Hq, D, generator=g, device=dev).to(torch.bfloat16)
+    k = torch.randn(Bp * L, Hkv, D, generator=g, device=dev).to(torch.bfloat16)
+    v = torch.randn(Bp * L, Hkv, D, generator=g, device=dev).to(torch.bfloat16)
+    cu = torch.arange(0, (Bp + 1) * L, L, dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+    for _ in range(3):
+        ops.prefill_attention(q, k, v, cu, cu, L, L, D ** -0.5, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.prefill_attention(q, k, v, cu, cu, L, L, D ** -0.5, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = Bp * 4 * Hq * D * (L * L - L * (L - 1) // 2)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"workload": f"4 x 4096-token prompts, causal, packed, {Hq}q/{Hkv}kv heads, D=128", "ms": round(ms, 4),
+            "tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "bound": "mfma", "flops_per_launch": flops}
+
+
 def e2e_leg(n, port, mode, limit_s, tuned_gemms=False):
     """tools/e2e_bench.py in a child process group of its own (killed as a group at the limit).
     tuned_gemms: PyTorch's TunableOp picks the model's GEMM kernels from the committed selection
@@ -268,6 +298,11 @@ def main():
         case_cpu = (q.cpu(), kv[0, 0].cpu(), kv[1, 0].cpu(), ctx_cpu, bt_cpu, scale)
         result["cpu_baseline"] = cpu_baseline(case_cpu, Hq, Hkv)
     t_aux = time.perf_counter()
+    if rank == 0 and not args.no_aux:
+        try:
+            result["prefill"] = prefill_leg(torch, ops, dev, n)
+        except Exception as exc:   # reported, never fatal for the headline number
+            result["prefill"] = {"error": repr(exc)[:300]}
     if n > 1 and not args.no_aux:
         try:
             result["collectives"] = allreduce_bench(dist, dev, n)
