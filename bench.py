@@ -106,10 +106,13 @@ TUNED_GEMMS = os.path.join(ROOT, "tools", "tunable", "tunableop.csv")   # PyTorc
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X
 
 
-def prefill_leg(torch, ops, dev, n, iters=10):
+def prefill_leg(torch, ops, dev, n, iters=50, warmup=20):
     """Varlen causal prefill attention of the Qwen3-8B prefill configuration (4 x 4096-token
     prompts, packed) on this rank's TP head share: TFLOP/s of the algorithmic causal FLOP count
-    and the fraction of the dense bf16 matrix peak, timed with events on the launch stream."""
+    and the fraction of the dense bf16 matrix peak, timed with events on the launch stream.
+    The untimed launches bring the clocks to what a busy engine sees: from an idle GPU the first
+    ~10 ms of this matrix-bound kernel run ~19 % slower (measured: 10 launches 0.66 ms each, 100
+    launches 0.555 ms each, same operands)."""
     Hq, Hkv, L, Bp = max(32 // n, 1), max(8 // n, 1), 4096, 4
     g = torch.Generator(device=dev).manual_seed(1)
     q = torch.randn(Bp * L, Hq, D, generator=g, device=dev).to(torch.bfloat16)
@@ -117,7 +120,7 @@ def prefill_leg(torch, ops, dev, n, iters=10):
     v = torch.randn(Bp * L, Hkv, D, generator=g, device=dev).to(torch.bfloat16)
     cu = torch.arange(0, (Bp + 1) * L, L, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
-    for _ in range(3):
+    for _ in range(warmup):
         ops.prefill_attention(q, k, v, cu, cu, L, L, D ** -0.5, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -128,7 +131,8 @@ def prefill_leg(torch, ops, dev, n, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = Bp * 4 * Hq * D * (L * L - L * (L - 1) // 2)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"workload": f"4 x 4096-token prompts, causal, packed, {Hq}q/{Hkv}kv heads, D=128", "ms": round(ms, 4),
+    return {"workload": f"4 x 4096-token prompts, causal, packed, {Hq}q/{Hkv}kv heads, D=128",
+            "launches": iters, "untimed_launches": warmup, "ms": round(ms, 4),
             "tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "bound": "mfma", "flops_per_launch": flops}
 

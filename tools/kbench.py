@@ -85,20 +85,27 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
 
-def prefill_case(lens, Hq, Hkv, paged_prefix=0):
+def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
     total = sum(lens)
-    q = torch.randn(total, Hq, D, device=dev).to(torch.bfloat16)
-    k = torch.randn(total, Hkv, D, device=dev).to(torch.bfloat16)
-    v = torch.randn(total, Hkv, D, device=dev).to(torch.bfloat16)
+
+    def draw(h):
+        if data == "uniform":      # uniform in [-2, 2), as tools/prefill_diag.hip
+            return (torch.rand(total, h, D, device=dev) * 4 - 2).to(torch.bfloat16)
+        if data == "zeros":
+            return torch.zeros(total, h, D, dtype=torch.bfloat16, device=dev)
+        return torch.randn(total, h, D, device=dev).to(torch.bfloat16)
+    q, k, v = draw(Hq), draw(Hkv), draw(Hkv)
     cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
 
     def fn():
         ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out)
 
-    t = timeit(fn, iters=10, warmup=2)
+    # matrix-bound kernels run ~19 % slower for the first ~10 ms after an idle GPU (clock ramp):
+    # 20 untimed launches first, so that the timed ones see the clocks a busy engine has
+    t = timeit(fn, iters=iters, warmup=20)
     flops = sum(4 * Hq * D * (L * L - L * (L - 1) // 2) for L in lens)
-    return dict(kind="prefill", lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
+    return dict(kind="prefill", data=data, iters=iters, lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
 
 
@@ -126,6 +133,10 @@ def main():
         rows.append(prefill_case([4096, 3000, 1024, 8264], 32, 8))
         rows.append(prefill_case([1024] * 16, 16, 8))
         rows.append(prefill_case([4096] * 4, 8, 1))
+    if args.what == "prefill_data":      # same launch, different operand values and burst lengths
+        for data in ("normal", "uniform", "zeros"):
+            for iters in (10, 100):
+                rows.append(prefill_case([4096] * 4, 32, 8, data=data, iters=iters))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_g8":
