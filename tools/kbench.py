@@ -137,6 +137,10 @@ def main():
         for data in ("normal", "uniform", "zeros"):
             for iters in (10, 100):
                 rows.append(prefill_case([4096] * 4, 32, 8, data=data, iters=iters))
+    if args.what == "prefill_shapes":    # the shapes the kernel choice is made on
+        for lens, Hq, Hkv in (([512] * 32, 32, 8), ([1024] * 16, 32, 8), ([1536] * 10, 32, 8), ([2048] * 8, 32, 8),
+                              ([4096] * 4, 32, 8), ([1024] * 16, 16, 8), ([2048] * 8, 4, 1)):
+            rows.append(prefill_case(lens, Hq, Hkv))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_g8":
