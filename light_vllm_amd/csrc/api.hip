@@ -23,29 +23,35 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxSplits = 512;
 constexpr int kSplitUnitTokens = 64;  // split granularity of the decode kernel
 constexpr int kFillWorkgroups = 256;      // one workgroup per CU
-constexpr int kLongSplitTokens = 1024;    // a split longer than this is cut further ...
-constexpr int kMaxWorkgroups = 2048;      // ... while the launch stays below this many workgroups
+constexpr int kTargetStreams = 256;       // sequences x splits the HBM channels want to see at once
+constexpr int kMinCutTokens = 512;        // ... but no split made for that reason shorter than this
+constexpr int kMaxWorkgroups = 4096;
 constexpr int kSaturatedUnits = 1024;     // (sequence, kv head) pairs that fill the chip unsplit
 
 // Split count from the launch shape alone (lengths live on the device; `max_blocks_per_seq` is
-// the table capacity). Fitted to a sweep under hipGraph replay over 1-32 sequences, 1-8 kv heads
-// and 1k-32k tokens: the best count puts about one workgroup on every CU, cuts splits that would
-// be longer than ~1024 tokens while the launch has fewer than ~2048 workgroups, and never goes
-// below the kernel's 64-token split unit. (32768 tokens, 1 sequence, 4q/1kv: 512 splits 16.4 us,
-// 256 splits 12.6 us, 8 splits 60 us; 8 sequences, 32q/8kv: 4 splits 240 us, 32 splits 170 us.)
+// the table capacity). Fitted to sweeps under hipGraph replay (tools/kbench.py decode_splits,
+// decode_mid, decode_tp: 1-256 sequences, 1-8 kv heads, 1k-32k tokens), two needs:
+//   fill     at least one workgroup per CU: ceil(256 / (batch * kv heads));
+//   streams  about 256 independent (sequence, split) streams, whatever the head count - what
+//            matters is how many places of the cache are read at once: 64 sequences x 4096
+//            tokens x 8 kv heads run 9 % faster cut in 4, 64 x 32768 x 4 heads 12 %, while 256
+//            sequences never gain from a cut (-3 ... -8 %) - but no such split under 512 tokens.
+// The larger of the two, never below the kernel's 64-token split unit. Within 4 % of the best
+// count on every shape of the sweeps (the first rule, 1024 workgroups always: up to 30 % off).
 static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {
   const int64_t units = static_cast<int64_t>(batch) * num_kv_heads;
   if (units <= 0 || max_blocks_per_seq <= 0) return 1;
   if (units >= kSaturatedUnits) return 1;
   const int64_t cap_tokens = static_cast<int64_t>(max_blocks_per_seq) * block_size;
   const int64_t fill = (kFillWorkgroups + units - 1) / units;
-  int64_t cut = (cap_tokens + kLongSplitTokens - 1) / kLongSplitTokens;
-  const int64_t cut_limit = kMaxWorkgroups / units > 1 ? kMaxWorkgroups / units : 1;
-  if (cut > cut_limit) cut = cut_limit;
-  int64_t n = fill > cut ? fill : cut;
+  int64_t streams = (kTargetStreams + batch - 1) / batch;
+  const int64_t longest = cap_tokens / kMinCutTokens > 1 ? cap_tokens / kMinCutTokens : 1;
+  if (streams > longest) streams = longest;
+  int64_t n = fill > streams ? fill : streams;
   const int64_t max_n = (cap_tokens + kSplitUnitTokens - 1) / kSplitUnitTokens;
   if (n > max_n) n = max_n;
   if (n > kMaxSplits) n = kMaxSplits;
+  if (n * units > kMaxWorkgroups) n = kMaxWorkgroups / units;
   return n < 1 ? 1 : static_cast<int>(n);
 }
 

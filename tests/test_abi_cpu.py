@@ -43,7 +43,9 @@ def test_host_only_entry_points():
     assert lib.lv_decode_num_splits(1, 1, 128, 256) == 256    # one long sequence: a workgroup per CU
     assert lib.lv_decode_num_splits(8, 8, 128, 256) == 32     # 32k-token capacity: ~1024 tokens per split
     assert lib.lv_decode_num_splits(1, 8, 1, 256) == 4        # a single block: the kernel's 64-token unit
-    assert lib.lv_decode_num_splits(64, 8, 16, 256) == 4      # long splits are cut while the launch is small
+    assert lib.lv_decode_num_splits(64, 8, 16, 256) == 4      # 64 sequences: cut in 4 for ~256 read streams
+    assert lib.lv_decode_num_splits(256, 1, 16, 256) == 1     # 256 sequences are streams enough
+    assert lib.lv_decode_num_splits(8, 1, 16, 256) == 32      # few units: one workgroup per CU
 
 
 def test_argument_validation_happens_before_any_launch():

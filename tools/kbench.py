@@ -186,6 +186,15 @@ def main():
                                                   cs, kc, vc, slots))
         nbytes = N * D * 2 * (2 * Hq + 2 * Hkv + Hkv + 2 * Hkv)
         rows.append(dict(kind="qk_norm_rope_store", N=N, Hq=Hq, Hkv=Hkv, us=round(t * 1e6, 1), GBs=round(nbytes / t / 1e9, 1)))
+    if args.what == "decode_mid":        # launches around the point where splitting stops paying
+        for (B, ctx, Hq, Hkv) in [(64, 4096, 32, 8), (32, 4096, 32, 8), (16, 4096, 32, 8), (128, 4096, 4, 1), (64, 32768, 16, 4)]:
+            for ns in (0, 1, 2, 4):
+                rows.append(decode_case(B, ctx, Hq, Hkv, nsplit=ns, graph=True))
+    if args.what == "decode_tp":         # per-rank shapes of Qwen3-8B at TP = 2 / 4 / 8, batch 256
+        for (Hq, Hkv) in [(16, 4), (8, 2), (4, 1)]:
+            for ctx in (1024, 4096):
+                for ns in (0, 1, 2, 4, 8):
+                    rows.append(decode_case(256, ctx, Hq, Hkv, nsplit=ns, graph=True))
     if args.what == "decode_splits":     # split-count sweep around the heuristic, hipGraph replay
         for (Hq, Hkv) in [(4, 1), (16, 4), (32, 8)]:
             for (B, ctx) in [(1, 32768), (8, 32768), (1, 4096), (8, 4096), (32, 4096), (1, 1024), (8, 1024)]:
