@@ -186,6 +186,8 @@ def main():
                                                   cs, kc, vc, slots))
         nbytes = N * D * 2 * (2 * Hq + 2 * Hkv + Hkv + 2 * Hkv)
         rows.append(dict(kind="qk_norm_rope_store", N=N, Hq=Hq, Hkv=Hkv, us=round(t * 1e6, 1), GBs=round(nbytes / t / 1e9, 1)))
+    if args.what == "decode_b1":         # one long sequence: split pass vs merge pass (profile this one)
+        rows.append(decode_case(1, 32768, int(os.environ.get("KB_HQ", "4")), int(os.environ.get("KB_HKV", "1")), graph=True))
     if args.what == "decode_mid":        # launches around the point where splitting stops paying
         for (B, ctx, Hq, Hkv) in [(64, 4096, 32, 8), (32, 4096, 32, 8), (16, 4096, 32, 8), (128, 4096, 4, 1), (64, 32768, 16, 4)]:
             for ns in (0, 1, 2, 4):
