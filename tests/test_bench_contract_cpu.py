@@ -1,0 +1,37 @@
+"""bench.py's accounting, checked without a GPU: the algorithmic byte counts the roofline figure
+is built from, the split-count the workload runs with, and the command-line contract."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_decode_bytes_of_the_headline_workload():
+    b = _bench()
+    # B=256, ctx=1024, 16 q / 8 kv heads, D=128, 256-token blocks: K+V rows read once
+    # (1 073 741 824 B), q in and o out (2 097 152 B), context_lens (1024 B), block-table
+    # entries touched (4096 B)
+    assert b.decode_bytes(256, 1024, 16, 8) == 1_075_844_096
+    assert b.store_bytes(256, 8) == 2 * (256 * 8 * 128 * 2 * 2) + 4 * 256
+
+
+def test_prefill_flops_of_config3():
+    # 4 x 4096 tokens, 32 q heads: sum_b 4 Hq D (Lq Lk - Lq (Lq - 1) / 2) = 549.9 GFLOP
+    L, Hq, D = 4096, 32, 128
+    assert 4 * 4 * Hq * D * (L * L - L * (L - 1) // 2) == 549_890_031_616
+
+
+def test_cli_rejects_inconsistent_world_size():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
