@@ -181,7 +181,8 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
  * cache_seqlens=context_lens, block_table=block_tables, softmax_scale, causal=True)
  * — attention.py:172-175.
  *
- *   q, o          [batch, num_heads, head_dim], row strides q_stride0 / o_stride0
+ *   q, o          [batch, num_heads, head_dim], row strides q_stride0 / o_stride0;
+ *                 num_heads / num_kv_heads must be 1..8 (LV_ERR_UNSUPPORTED otherwise)
  *   k_cache, v_cache  [num_blocks, block_size, num_kv_heads, head_dim] contiguous
  *   context_lens  int32 [batch]; sequence b attends to cache tokens [0, context_lens[b]),
  *                 which already include the token stored by this step's lv_store_kvcache.

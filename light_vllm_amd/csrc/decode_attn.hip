@@ -605,8 +605,14 @@ int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
     case 2: if (mfma) launch_mfma<2>(p, stream); else launch_g<2, 8>(p, stream); break;
     case 4: if (mfma) launch_mfma<4>(p, stream); else launch_g<4, 4>(p, stream); break;
     case 8: if (mfma) launch_mfma<8>(p, stream); else launch_g<8, 4>(p, stream); break;
+    // other group sizes (Qwen3-14B has 40 q / 8 kv heads = 5): the matrix-core kernel only, its
+    // head dimension is a 16-column tile of which G columns are live
+    case 3: launch_mfma<3>(p, stream); break;
+    case 5: launch_mfma<5>(p, stream); break;
+    case 6: launch_mfma<6>(p, stream); break;
+    case 7: launch_mfma<7>(p, stream); break;
     default:
-      return fail(LV_ERR_UNSUPPORTED, "decode: num_heads/num_kv_heads = %d not in {1,2,4,8}", G);
+      return fail(LV_ERR_UNSUPPORTED, "decode: num_heads/num_kv_heads = %d not in 1..8", G);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_attn launch: %s", hipGetErrorString(e));

@@ -179,3 +179,11 @@ def test_decode_seq_order_grouped_batches(gpu, B, Hq, Hkv):
         ops.decode_attention(*args, num_splits=ns, out=out, seq_order=so)
         assert torch.equal(out, ref)
     _check(gpu, case)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(40, 8), (5, 1), (3, 1), (6, 1), (7, 1), (12, 2)])
+def test_decode_other_group_sizes(gpu, Hq, Hkv):
+    """Group sizes 3, 5, 6, 7 (Qwen3-14B: 40 q / 8 kv heads) run on the matrix-core kernel."""
+    case = make_decode_case(23, [5, 300, 257, 64, 1000], Hq, Hkv)
+    _check(gpu, case)
+    _check(gpu, case, num_splits=3)

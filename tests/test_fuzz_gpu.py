@@ -10,7 +10,8 @@ from tests._cases import make_decode_case, make_prefill_case, to_dev
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-2
-GROUPS = [(1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (8, 4), (16, 8), (32, 8), (16, 4), (64, 8)]
+GROUPS = [(1, 1), (2, 1), (4, 1), (8, 1), (2, 2), (8, 4), (16, 8), (32, 8), (16, 4), (64, 8),
+          (3, 1), (5, 1), (40, 8), (6, 1), (7, 1), (12, 2)]
 
 
 def _lengths(g, n, hi):
@@ -25,7 +26,7 @@ def _lengths(g, n, hi):
     return out
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(40))
 def test_fuzz_decode(gpu, monkeypatch, seed):
     from light_vllm_amd import ops
     g = torch.Generator().manual_seed(1000 + seed)
@@ -36,7 +37,7 @@ def test_fuzz_decode(gpu, monkeypatch, seed):
     if torch.rand((), generator=g).item() < 0.3:
         lens[int(torch.randint(0, B, (), generator=g))] = 0          # an empty row
     ns = [0, 1, 2, 3, 5][int(torch.randint(0, 5, (), generator=g))]
-    if Hq // Hkv <= 8 and torch.rand((), generator=g).item() < 0.5:  # either kernel for any group size
+    if Hq // Hkv in (1, 2, 4, 8) and torch.rand((), generator=g).item() < 0.5:  # either kernel for these group sizes
         monkeypatch.setenv("LV_DECODE_MFMA", str(int(torch.randint(0, 2, (), generator=g))))
     case = make_decode_case(2000 + seed, lens, Hq, Hkv, block_size=block, pad_cols=int(torch.randint(0, 3, (), generator=g)))
     d = to_dev(case, gpu)
