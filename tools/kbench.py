@@ -141,6 +141,10 @@ def main():
         for lens, Hq, Hkv in (([512] * 32, 32, 8), ([1024] * 16, 32, 8), ([1536] * 10, 32, 8), ([2048] * 8, 32, 8),
                               ([4096] * 4, 32, 8), ([1024] * 16, 16, 8), ([2048] * 8, 4, 1)):
             rows.append(prefill_case(lens, Hq, Hkv))
+    if args.what == "prefill_small":     # grids that fit the chip at once (TP = 8 shapes)
+        for lens, Hq, Hkv in (([2048] * 8, 4, 1), ([4096] * 4, 4, 1), ([1024] * 16, 4, 1), ([4096] * 2, 8, 2),
+                              ([1024] * 16, 32, 8), ([4096] * 4, 32, 8)):
+            rows.append(prefill_case(lens, Hq, Hkv))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_g8":
