@@ -2,6 +2,8 @@
 seeded random combinations of batch size, lengths (short, block-boundary and long), head
 grouping, block size, split count, launch order and kernel choice — the corners between the
 hand-picked cases of the other GPU tests. Tolerance as there: max-abs <= 2e-2 on bf16 outputs."""
+import os
+
 import pytest
 import torch
 
@@ -26,7 +28,7 @@ def _lengths(g, n, hi):
     return out
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LV_FUZZ_DECODE", "40"))))   # more seeds for a soak run
 def test_fuzz_decode(gpu, monkeypatch, seed):
     from light_vllm_amd import ops
     g = torch.Generator().manual_seed(1000 + seed)
@@ -55,7 +57,7 @@ def test_fuzz_decode(gpu, monkeypatch, seed):
             assert bool((out[b] == 0).all())
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LV_FUZZ_PREFILL", "20"))))
 def test_fuzz_prefill(gpu, monkeypatch, seed):
     from light_vllm_amd import ops
     g = torch.Generator().manual_seed(3000 + seed)
