@@ -672,6 +672,15 @@ void prefill_pp_kernel(const PrefillParams p) {
   const int xr = ((c & 3) << 2) | ((c >> 2) & 3);
   const int kbase0 = (256 * c) | (16 * (h ^ xr));
   bf16x8 qf[8];
+  // softmax scale * log2(e) = q_pow * c2 with q_pow a power of two and 1 <= c2 < 2: Q is multiplied
+  // by q_pow only, which is exact in bf16 (the full factor would round every element of Q to 8
+  // bits again: on scores of magnitude ~30 that alone moved outputs by up to 0.12), and c2 is
+  // applied in fp32 where the exponentials are taken. Scores, running maxima and the deferral
+  // threshold are kept in units of 1 / c2.
+  const float q_pow = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p.scale_log2e) & 0xff800000u);
+  const float c2 = p.scale_log2e / q_pow;
+  const float defer_s = kDeferLog2 / c2;
+
   {
     const int row_ld = min(my_row, Lq - 1);
     const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
@@ -681,7 +690,7 @@ void prefill_pp_kernel(const PrefillParams p) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * p.scale_log2e);
+      for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * q_pow);
       asm volatile("" ::"v"(qf[s]));   // retire the loads before the tile loop
     }
   }
@@ -850,12 +859,12 @@ void prefill_pp_kernel(const PrefillParams p) {
       const float m_off = fresh ? 0.f : m_run;
       const float m_new = fmaxf(m_run, m_off + mx);
       const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_off;
-      const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      const float alpha = fresh ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * c2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[r] -= delta; sb[r] -= delta; }
       l_run *= alpha;
       m_run = m_new;
-      defer_thr = (m_new == -INFINITY) ? -INFINITY : kDeferLog2;
+      defer_thr = (m_new == -INFINITY) ? -INFINITY : defer_s;
       pend_alpha = alpha;
       pend = true;
     }
@@ -867,7 +876,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     if (LV_ABL & 512) { if (Q == 0) { asm volatile("" : "=v"(pf[0])); asm volatile("" : "=v"(pf[1])); } return; }
 #pragma unroll
     for (int r = 4 * Q; r < 4 * Q + 4; ++r) {
-      const float pe = (LV_ABL & 1) ? sacc[r] : __builtin_amdgcn_exp2f(sacc[r]);
+      const float pe = (LV_ABL & 1) ? sacc[r] : __builtin_amdgcn_exp2f(sacc[r] * c2);
       psum += pe;
       pf[r >> 3][r & 7] = static_cast<__bf16>(pe);
     }
