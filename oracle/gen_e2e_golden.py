@@ -96,6 +96,13 @@ def install_stubs():
     sys.modules["lightvllm.kernels.cuda_kernels"] = ck
 
 
+def long_prompts():
+    """Two prompts beyond 2048 tokens (2100 and 2500): the prefill call takes the long-prompt
+    kernel choice, and decode reads 9-10 blocks per sequence."""
+    g = torch.Generator().manual_seed(78)
+    return [torch.randint(0, 151936, (n,), generator=g).tolist() for n in (2100, 2500)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=28)
@@ -103,7 +110,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "e2e_config1.json"))
     ap.add_argument("--shape", default="0.6b", choices=["0.6b", "gqa4"])
-    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix"])
+    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix", "long"])
     args = ap.parse_args()
 
     install_stubs()
@@ -125,7 +132,7 @@ def main():
     load_random(model, hf, args.seed)
     sampler = Sampler()
 
-    block_size, num_blocks = 256, 16
+    block_size, num_blocks = 256, (24 if args.scenario == "long" else 16)
     kv = torch.zeros(2, hf.num_hidden_layers, num_blocks, block_size, hf.num_key_value_heads, hf.head_dim,
                      dtype=torch.bfloat16)
     layer_id = 0
@@ -138,7 +145,7 @@ def main():
                           num_kvcache_blocks=num_blocks, kvcache_block_size=block_size)
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=args.steps, ignore_eos=True)
-    prompts = config1_prompts() if args.scenario == "config1" else prefix_prompts()
+    prompts = {"config1": config1_prompts, "prefix": prefix_prompts, "long": long_prompts}[args.scenario]()
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
     for s in seqs:

@@ -61,3 +61,21 @@ def test_prefix_cache_scenario_matches_reference_stack():
     assert compared == 4 * golden["max_tokens"]
     assert not hard, f"token mismatches outside ties: {hard}"
     assert len(soft) <= 2, f"too many tie flips: {soft}"
+
+
+def test_long_prompt_scenario_matches_reference_stack():
+    """Two prompts of 2100 and 2500 tokens in one prefill batch, then decode over 9-10 blocks per
+    sequence (32 q / 8 kv heads), against the reference stack's recorded run."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from tests._e2e import golden_config
+    golden = load_golden("e2e_long_gqa4.json")
+    with cpu_kernels():
+        cfg = Config(None, hf_config=golden_config(golden), device="cpu", num_kvcache_blocks=24,
+                     max_model_len=4096, max_num_batched_tokens=8192, random_seed=golden["seed"])
+        runner = ModelRunner(cfg, 0, [])
+        compared, soft, hard, _ = replay(golden, runner, Scheduler(cfg), tie_ulps=2)
+    assert compared == 2 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert len(soft) <= 2, f"too many tie flips: {soft}"
