@@ -178,3 +178,36 @@ def test_graph_padding_rows_match_eager(gpu):
     for a, b in zip(runs[0], runs[1]):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 0.06
+
+
+def test_preemption_and_recompute_on_gpu(gpu):
+    """Six sequences that outgrow a 14-block cache: the scheduler preempts (LIFO), the preempted
+    sequences are prefilled again with their generated tokens, every block returns to the free
+    list, and the completions start like those of a run with ample cache (greedy; where they
+    part, at least 32 tokens in, is a near-tie of recomputed against incremental logits)."""
+    from light_vllm_amd.llm import LLM
+    from light_vllm_amd.sampling_params import SamplingParams
+    from tests._e2e import gqa4_config
+    g = torch.Generator().manual_seed(21)
+    prompts = [torch.randint(0, 151936, (300,), generator=g).tolist() for _ in range(6)]
+    sp = SamplingParams(temperature=0.0, max_tokens=300, ignore_eos=True)
+    outs, preemptions = {}, {}
+    for blocks in (64, 14):
+        llm = LLM(None, hf_config=gqa4_config(4), num_kvcache_blocks=blocks, max_num_seqs=16, enforce_eager=False,
+                  random_seed=3)
+        count = [0]
+        original = llm.scheduler.preempt
+
+        def counted(seq, original=original, count=count):
+            count[0] += 1
+            return original(seq)
+        llm.scheduler.preempt = counted
+        outs[blocks] = [r["token_ids"] for r in llm.generate(prompts, sp)]
+        preemptions[blocks] = count[0]
+        assert len(llm.scheduler.block_manager.free_block_ids) == blocks
+        llm.exit()
+    assert preemptions[64] == 0 and preemptions[14] >= 1
+    assert all(len(t) == 300 for t in outs[14])
+    for a, b in zip(outs[64], outs[14]):
+        agree = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), len(a))
+        assert agree >= 32
