@@ -35,7 +35,20 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 4
+#define LV_ABI_VERSION 5
+
+/* kernel_hint of lv_decode_attn: which of the two decode kernels serves the call. */
+#define LV_DECODE_KERNEL_AUTO 0   /* by num_heads / num_kv_heads: vector-ALU for 1-2, matrix-core for 3-8 */
+#define LV_DECODE_KERNEL_VALU 1   /* vector-ALU kernel (group sizes 1, 2, 4, 8 only) */
+#define LV_DECODE_KERNEL_MFMA 2   /* matrix-core kernel (every group size 1..8) */
+
+/* kernel_hint of lv_prefill_attn: which prefill kernel serves the call. */
+#define LV_PREFILL_KERNEL_AUTO 0  /* by max_seqlen_q: W4 up to 1024, W8 below 2048, PP from 2048 */
+#define LV_PREFILL_KERNEL_W4 1    /* 4 waves x 32 query rows, two workgroups per CU */
+#define LV_PREFILL_KERNEL_W8 2    /* 8 waves x 32 query rows */
+#define LV_PREFILL_KERNEL_PP 3    /* 8 waves in two phase-locked groups (long prompts) */
+#define LV_PREFILL_KERNEL_W64 5   /* 4 waves x 64 query rows, one wave per SIMD */
+#define LV_PREFILL_STAGE_DMA 0x100 /* or-ed to W4 / W8: stage K/V tiles with direct-to-LDS loads */
 
 typedef void* lv_stream_t;
 
@@ -153,7 +166,10 @@ int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_str
  *   bf16 inputs, fp32 scores / softmax statistics / accumulation, bf16 output.
  *   A query row that sees no key (Lk_b < Lq_b rows) is written as zeros.
  * max_seqlen_q bounds the grid (rows beyond a sequence's Lq_b exit early); max_seqlen_k is
- * accepted for signature parity and only validated.
+ * accepted for signature parity and only validated. scale must be finite and > 0.
+ * kernel_hint: LV_PREFILL_KERNEL_AUTO, or one of the LV_PREFILL_KERNEL_* values to force that
+ * kernel (every one of them computes the same function; the choice is a performance matter and
+ * what the parity tests iterate over). No counterpart in the reference call.
  */
 int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
@@ -161,7 +177,7 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int batch, int max_seqlen_q, int max_seqlen_k,
                     const int32_t* block_table, int block_table_stride, int block_size,
                     int num_heads, int num_kv_heads, int head_dim, float scale,
-                    lv_stream_t stream);
+                    int kernel_hint, lv_stream_t stream);
 
 /*
  * Split count lv_decode_attn will use when called with num_splits == 0, for these static
@@ -204,8 +220,15 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
  *                 outside [0, batch) are skipped (that sequence's output is then not written).
  *                 No counterpart in the reference call; a caller that has no lengths on the
  *                 host passes NULL.
+ *   kernel_hint   LV_DECODE_KERNEL_AUTO, or _VALU / _MFMA to force one of the two kernels (same
+ *                 function; a performance matter and what the parity tests iterate over).
+ *   scale         finite and > 0.
  *
  * bf16 inputs, fp32 scores / online softmax / accumulation, bf16 output.
+ *
+ * The workspace is written by the split kernel and read by the merge kernel of the same call.
+ * Calls that share one workspace must therefore be ordered on ONE stream (one workspace per
+ * device and stream); two streams decoding concurrently need a workspace each.
  */
 int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* o,
                    int64_t q_stride0, int64_t o_stride0,
@@ -214,7 +237,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    int batch, int max_blocks_per_seq, int block_size,
                    int num_heads, int num_kv_heads, int head_dim, float scale,
                    void* workspace, size_t workspace_bytes, int num_splits,
-                   const int32_t* seq_order, lv_stream_t stream);
+                   const int32_t* seq_order, int kernel_hint, lv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvattn.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); must list every symbol include/lv_attention.h declares.
 SIGNATURES = {
@@ -29,12 +29,12 @@ SIGNATURES = {
     "lv_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "lv_prefill_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
-                                c_int, c_int, c_int, c_float, c_void_p]),
+                                c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "lv_decode_num_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "lv_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lv_decode_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                               c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
+                               c_void_p, c_size_t, c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -1,5 +1,6 @@
 // C-ABI entry points of liblvattn.so (declared in include/lv_attention.h): argument validation
 // on the host, then stream-ordered kernel launches. Nothing here synchronises or allocates.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -188,12 +189,14 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
                     const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
                     int max_seqlen_q, int max_seqlen_k, const int32_t* block_table,
                     int block_table_stride, int block_size, int num_heads, int num_kv_heads,
-                    int head_dim, float scale, lv_stream_t stream) {
+                    int head_dim, float scale, int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || num_heads <= 0 || num_kv_heads <= 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "prefill: head_dim %d != 128", head_dim);
   if (num_heads % num_kv_heads != 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: num_heads %% num_kv_heads != 0");
+  if (!isfinite(scale) || scale <= 0.f)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: scale %g must be finite and > 0", (double)scale);
   if (batch == 0 || max_seqlen_q == 0) return LV_OK;
   if (!q || !k || !v || !o || !cu_seqlens_q || !cu_seqlens_k)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: null pointer");
@@ -230,6 +233,7 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
   p.max_seqlen_q = max_seqlen_q;
   p.num_heads = num_heads;
   p.num_kv_heads = num_kv_heads;
+  p.kernel_hint = kernel_hint;
   p.scale_log2e = scale * kLog2e;
   return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
 }
@@ -243,12 +247,15 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
   return static_cast<size_t>(batch) * num_heads * num_splits * (kHeadDim + 2) * sizeof(float);
 }
 
-int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* o,
-                   int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
-                   const int32_t* block_table, int block_table_stride, int batch,
-                   int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
-                   int head_dim, float scale, void* workspace, size_t workspace_bytes,
-                   int num_splits, const int32_t* seq_order, lv_stream_t stream) {
+}  // extern "C"
+
+static int decode_entry(const void* q, const void* k_cache, const void* v_cache, void* o,
+                        int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
+                        const int32_t* block_table, int block_table_stride, int batch,
+                        int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
+                        int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                        int num_splits, const int32_t* seq_order,
+                        int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_blocks_per_seq < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_splits < 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "decode: head_dim %d != 128", head_dim);
@@ -256,6 +263,16 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: num_heads %% num_kv_heads != 0");
   if (block_size <= 0 || block_size % 32 != 0)
     return fail(LV_ERR_UNSUPPORTED, "decode: block_size %d must be a positive multiple of 32", block_size);
+  if (!isfinite(scale) || scale <= 0.f)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: scale %g must be finite and > 0", (double)scale);
+  if (kernel_hint != LV_DECODE_KERNEL_AUTO && kernel_hint != LV_DECODE_KERNEL_VALU &&
+      kernel_hint != LV_DECODE_KERNEL_MFMA)
+    return fail(LV_ERR_INVALID_ARGUMENT, "decode: kernel_hint %d", kernel_hint);
+  {
+    const int group = num_heads / num_kv_heads;
+    if (kernel_hint == LV_DECODE_KERNEL_VALU && group != 1 && group != 2 && group != 4 && group != 8)
+      return fail(LV_ERR_UNSUPPORTED, "decode: the vector-ALU kernel serves group sizes 1, 2, 4, 8, not %d", group);
+  }
   if (batch == 0) return LV_OK;
   if (!q || !k_cache || !v_cache || !o || !context_lens || !block_table)
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: null pointer");
@@ -297,8 +314,23 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
   p.num_heads = num_heads;
   p.num_kv_heads = num_kv_heads;
   p.nsplit = nsplit;
+  p.kernel_hint = kernel_hint;
   p.scale_log2e = scale * kLog2e;
   return launch_decode_attn(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" {
+
+int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void* o,
+                   int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
+                   const int32_t* block_table, int block_table_stride, int batch,
+                   int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
+                   int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                   int num_splits, const int32_t* seq_order, int kernel_hint, lv_stream_t stream) {
+  return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
+                      block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
+                      num_kv_heads, head_dim, scale, workspace, workspace_bytes, num_splits,
+                      seq_order, kernel_hint, stream);
 }
 
 }  // extern "C"

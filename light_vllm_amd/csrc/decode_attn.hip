@@ -15,8 +15,6 @@
 //     (fp32 workspace + a small merge kernel) with the usual (m, l) rescaling rule;
 //   * the grid depends only on static shapes (batch, kv heads, splits); each workgroup derives
 //     its token range from context_lens on device, so the launch is hipGraph-replay safe.
-#include <stdlib.h>
-
 #include "lv_kernels.h"
 
 namespace lv {
@@ -595,11 +593,9 @@ static void launch_mfma(const DecodeParams& p, hipStream_t stream) {
 int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
   const int G = p.num_heads / p.num_kv_heads;
   // Kernel choice: the matrix-core kernel for 4 and 8 query heads per kv head, the vector-ALU
-  // kernel for 1 and 2. LV_DECODE_MFMA=0 / 1 forces one of them for every group size (read on
-  // every call: tests switch it).
-  const char* env = getenv("LV_DECODE_MFMA");
-  const int force = env ? atoi(env) : -1;
-  const bool mfma = force >= 0 ? force != 0 : G >= 4;
+  // kernel for 1 and 2, unless the caller's kernel_hint names one of them.
+  const bool mfma = p.kernel_hint == LV_DECODE_KERNEL_MFMA ||
+                    (p.kernel_hint == LV_DECODE_KERNEL_AUTO && G >= 4);
   switch (G) {
     case 1: if (mfma) launch_mfma<1>(p, stream); else launch_g<1, 8>(p, stream); break;
     case 2: if (mfma) launch_mfma<2>(p, stream); else launch_g<2, 8>(p, stream); break;

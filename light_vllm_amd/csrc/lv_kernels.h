@@ -17,6 +17,7 @@ struct DecodeParams {
   const int32_t* seq_order;  // optional launch order of the sequences (nullptr = identity)
   int64_t q_stride0, o_stride0;
   int bt_stride, batch, block_size, num_heads, num_kv_heads, nsplit;
+  int kernel_hint;           // LV_DECODE_KERNEL_*
   float scale_log2e;
 };
 
@@ -30,6 +31,7 @@ struct PrefillParams {
   const int32_t* cu_k;
   const int32_t* block_table;  // nullptr = packed K/V
   int bt_stride, block_size, batch, max_seqlen_q, num_heads, num_kv_heads;
+  int kernel_hint;             // LV_PREFILL_KERNEL_* (| LV_PREFILL_STAGE_DMA)
   float scale_log2e;
 };
 

@@ -1619,12 +1619,19 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
   // cfg 2: the phase-locked 8-wave kernel (long prompts);
   // cfg 4: 4 waves x 64 rows, one wave per SIMD, asm-owned accumulator registers (opt-in).
-  // LV_PREFILL_CFG / LV_PREFILL_DMA override the choice (read on every call: tests switch them).
-  const char* env_cfg = getenv("LV_PREFILL_CFG");
-  const char* env_dma = getenv("LV_PREFILL_DMA");
-  const int force = env_cfg ? atoi(env_cfg) : -1;
-  const int cfg = force >= 0 ? force : (p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q > 1024 ? 1 : 0));
-  const int dma = env_dma ? atoi(env_dma) : 0;
+  // The caller's kernel_hint (LV_PREFILL_KERNEL_*, optionally | LV_PREFILL_STAGE_DMA) overrides
+  // the choice by prompt length.
+  const int want = p.kernel_hint & 0xff;
+  const int dma = (p.kernel_hint & LV_PREFILL_STAGE_DMA) != 0;
+  int cfg = p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q > 1024 ? 1 : 0);
+  switch (want) {
+    case LV_PREFILL_KERNEL_AUTO: break;
+    case LV_PREFILL_KERNEL_W4: cfg = 0; break;
+    case LV_PREFILL_KERNEL_W8: cfg = 1; break;
+    case LV_PREFILL_KERNEL_PP: cfg = 2; break;
+    case LV_PREFILL_KERNEL_W64: cfg = 4; break;
+    default: return fail(LV_ERR_INVALID_ARGUMENT, "prefill: kernel_hint %d", p.kernel_hint);
+  }
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
   } else if (cfg == 2) {

@@ -11,6 +11,20 @@ from . import _lib
 
 _BF16 = torch.bfloat16
 
+# kernel_hint values of include/lv_attention.h
+DECODE_KERNELS = {"auto": 0, "valu": 1, "mfma": 2}
+PREFILL_KERNELS = {"auto": 0, "w4": 1, "w8": 2, "pp": 3, "w64": 5, "w4_dma": 1 | 0x100, "w8_dma": 2 | 0x100}
+# Process-wide default for calls that do not name a kernel (the parity tests iterate over the
+# kernels by setting these; "valu" applies where that kernel exists, group sizes 1, 2, 4, 8).
+DEFAULT_KERNEL = {"decode": "auto", "prefill": "auto"}
+
+
+def _decode_hint(kernel: Optional[str], group: int) -> int:
+    name = kernel or DEFAULT_KERNEL["decode"]
+    if kernel is None and name == "valu" and group not in (1, 2, 4, 8):
+        name = "auto"
+    return DECODE_KERNELS[name]
+
 
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
@@ -59,11 +73,12 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                       cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
                       max_seqlen_q: int, max_seqlen_k: int, softmax_scale: float,
                       block_table: Optional[torch.Tensor] = None,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      out: Optional[torch.Tensor] = None, kernel: Optional[str] = None) -> torch.Tensor:
     """Varlen causal attention (bottom-right aligned mask), GQA, optional paged K/V.
 
     q: [total_q, Hq, D]. Packed mode: k/v [total_k, Hkv, D]. Paged mode (block_table given):
     k/v are the caches [num_blocks, block_size, Hkv, D] and block_table is int32 [B, max_blocks].
+    kernel: a key of PREFILL_KERNELS to force one kernel (default: DEFAULT_KERNEL["prefill"]).
     """
     dev = _require_gpu(q, k, v, cu_seqlens_q, cu_seqlens_k)
     total_q, Hq, D = q.shape
@@ -101,14 +116,20 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                                  q.stride(0), k_stride0, v_stride0, out.stride(0),
                                  cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), B,
                                  int(max_seqlen_q), int(max_seqlen_k), bt_ptr, bt_stride, block_size,
-                                 Hq, Hkv, D, float(softmax_scale), _stream_ptr(dev))
+                                 Hq, Hkv, D, float(softmax_scale),
+                                 PREFILL_KERNELS[kernel or DEFAULT_KERNEL["prefill"]], _stream_ptr(dev))
     _lib.check(rc, "lv_prefill_attn")
     return out
 
 
 # One split-KV workspace per device, shared by all layers (launches are stream-ordered and each
-# decode call finishes reading it in its own merge kernel before the next layer writes it).
+# decode call finishes reading it in its own merge kernel before the next layer writes it; callers
+# that decode on several streams of one device at once must pass their own `workspace`).
+# A buffer that has been handed to a launch is never freed: a captured hipGraph keeps the address
+# it was captured with, so a larger request retires the old buffer into _RETIRED instead of
+# dropping it.
 _WORKSPACE: Dict[int, torch.Tensor] = {}
+_RETIRED: list = []
 
 
 def decode_num_splits(batch: int, num_kv_heads: int, max_blocks_per_seq: int, block_size: int = 256) -> int:
@@ -121,11 +142,13 @@ def decode_workspace_bytes(batch: int, num_heads: int, head_dim: int, num_splits
 
 def reserve_decode_workspace(device: torch.device, nbytes: int) -> None:
     """Grow the cached workspace of `device` to at least nbytes. Call before hipGraph capture
-    with the largest (batch, splits) the graphs will see, so capture never has to allocate."""
+    with the largest (batch, splits) the process will see, so capture never has to allocate."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     cur = _WORKSPACE.get(idx)
     if cur is None or cur.numel() < nbytes:
+        if cur is not None:
+            _RETIRED.append(cur)
         _WORKSPACE[idx] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{idx}")
 
 
@@ -147,7 +170,8 @@ def _workspace(device: torch.device, nbytes: int) -> Tuple[Optional[int], int, O
 def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                      context_lens: torch.Tensor, block_table: torch.Tensor, softmax_scale: float,
                      num_splits: int = 0, out: Optional[torch.Tensor] = None,
-                     seq_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     seq_order: Optional[torch.Tensor] = None, kernel: Optional[str] = None,
+                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One query token per sequence over the paged cache.
 
     q: [B, Hq, D]; caches [num_blocks, block_size, Hkv, D] contiguous; context_lens int32 [B]
@@ -156,6 +180,8 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     seq_order: optional int32 [B] permutation, the order sequences are launched in (longest first
     evens out ragged batches; leave it out for batches of equal lengths, which run ~3 % faster in
     the default order); the result does not depend on it.
+    kernel: a key of DECODE_KERNELS to force one kernel (default: DEFAULT_KERNEL["decode"]).
+    workspace: caller-owned uint8 scratch for the split partials (default: the per-device one).
     """
     dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
     B, Hq, D = q.shape
@@ -180,14 +206,19 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         return out
     lib = _lib.load()
     nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks, block_size)
-    ws_ptr, ws_bytes, keep = _workspace(dev, lib.lv_decode_workspace_bytes(B, Hq, D, nsplit))
+    need = lib.lv_decode_workspace_bytes(B, Hq, D, nsplit)
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.device == dev and workspace.is_contiguous()
+        ws_ptr, ws_bytes, keep = workspace.data_ptr(), workspace.numel() * workspace.element_size(), workspace
+    else:
+        ws_ptr, ws_bytes, keep = _workspace(dev, need)
     with torch.cuda.device(dev):
         rc = lib.lv_decode_attn(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
                                 q.stride(0), out.stride(0), context_lens.data_ptr(),
                                 block_table.data_ptr(), block_table.stride(0), B, max_blocks, block_size,
                                 Hq, Hkv, D, float(softmax_scale), ws_ptr, ws_bytes, nsplit,
                                 seq_order.data_ptr() if seq_order is not None else None,
-                                _stream_ptr(dev))
+                                _decode_hint(kernel, Hq // Hkv), _stream_ptr(dev))
     _lib.check(rc, "lv_decode_attn")
     del keep
     return out

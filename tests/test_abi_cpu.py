@@ -56,13 +56,13 @@ def test_argument_validation_happens_before_any_launch():
     p = ctypes.addressof(buf)
     p16 = (p + 15) & ~15
     # head_dim 64 is not supported
-    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 64, 0.1, None, 0, 1, None, None)
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 64, 0.1, None, 0, 1, None, 0, None)
     assert rc == -2 and b"head_dim" in lib.lv_last_error()
     # block size must be a multiple of 32
-    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 48, 8, 8, 128, 0.1, None, 0, 1, None, None)
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 48, 8, 8, 128, 0.1, None, 0, 1, None, 0, None)
     assert rc == -2
     # split-KV without a workspace
-    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, 0.1, None, 0, 4, None, None)
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, 0.1, None, 0, 4, None, 0, None)
     assert rc == -4 and b"workspace" in lib.lv_last_error()
     # misaligned key pointer
     rc = lib.lv_store_kvcache(p16 + 2, p16, 1024, 1024, p16, p16, p16, 1, 8, 128, 256, None)
@@ -71,11 +71,21 @@ def test_argument_validation_happens_before_any_launch():
     rc = lib.lv_store_kvcache(p16, p16, 512, 1024, p16, p16, p16, 1, 8, 128, 256, None)
     assert rc == -1
     # heads not divisible
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 0, None)
     assert rc == -1
+    # scale must be finite and positive (a zero scale would turn the pre-scaled prefill kernel's constants into NaN)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 0, None)
+    assert rc == -1 and b"scale" in lib.lv_last_error()
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, float("nan"), None, 0, 1, None, 0, None)
+    assert rc == -1 and b"scale" in lib.lv_last_error()
+    # unknown kernel hints, and the vector-ALU decode kernel for a group size it does not serve
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, 0.1, None, 0, 1, None, 7, None)
+    assert rc == -1 and b"kernel_hint" in lib.lv_last_error()
+    rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 24, 8, 128, 0.1, None, 0, 1, None, 1, None)
+    assert rc == -2
     # zero-size calls are no-ops
     assert lib.lv_store_kvcache(None, None, 0, 0, None, None, None, 0, 8, 128, 256, None) == 0
-    assert lib.lv_decode_attn(None, None, None, None, 0, 0, None, None, 0, 0, 0, 256, 8, 8, 128, 0.1, None, 0, 1, None, None) == 0
+    assert lib.lv_decode_attn(None, None, None, None, 0, 0, None, None, 0, 0, 0, 256, 8, 8, 128, 0.1, None, 0, 1, None, 0, None) == 0
 
 
 def test_ops_refuse_cpu_tensors():

@@ -95,11 +95,12 @@ def test_decode_config2_shape_properties(gpu):
 
 
 # ---- The library picks the matrix-core kernel for 4 and 8 query heads per kv head and the
-# ---- vector-ALU kernel for 1 and 2; LV_DECODE_MFMA=0 / 1 forces one of them for every group size.
-@pytest.mark.parametrize("mfma", ["0", "1"])
+# ---- vector-ALU kernel for 1 and 2; the kernel hint forces one of them for every group size.
+@pytest.mark.parametrize("mfma", ["valu", "mfma"])
 @pytest.mark.parametrize("Hq,Hkv", [(8, 1), (64, 8), (16, 2), (4, 1), (32, 8), (16, 8), (8, 8)])
 def test_decode_wide_groups_both_kernels(gpu, monkeypatch, Hq, Hkv, mfma):
-    monkeypatch.setenv("LV_DECODE_MFMA", mfma)
+    from light_vllm_amd import ops
+    monkeypatch.setitem(ops.DEFAULT_KERNEL, "decode", mfma)
     lens = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1024, 700]
     _check(gpu, make_decode_case(12, lens, Hq, Hkv))
 

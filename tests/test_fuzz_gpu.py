@@ -40,7 +40,7 @@ def test_fuzz_decode(gpu, monkeypatch, seed):
         lens[int(torch.randint(0, B, (), generator=g))] = 0          # an empty row
     ns = [0, 1, 2, 3, 5][int(torch.randint(0, 5, (), generator=g))]
     if Hq // Hkv in (1, 2, 4, 8) and torch.rand((), generator=g).item() < 0.5:  # either kernel for these group sizes
-        monkeypatch.setenv("LV_DECODE_MFMA", str(int(torch.randint(0, 2, (), generator=g))))
+        monkeypatch.setitem(ops.DEFAULT_KERNEL, "decode", ["valu", "mfma"][int(torch.randint(0, 2, (), generator=g))])
     case = make_decode_case(2000 + seed, lens, Hq, Hkv, block_size=block, pad_cols=int(torch.randint(0, 3, (), generator=g)))
     d = to_dev(case, gpu)
     order = None
@@ -71,10 +71,7 @@ def test_fuzz_prefill(gpu, monkeypatch, seed):
     else:
         lens_k = list(lens_q)
     cfg = ["auto", "0", "1", "2", "4"][int(torch.randint(0, 5, (), generator=g))]
-    if cfg == "auto":
-        monkeypatch.delenv("LV_PREFILL_CFG", raising=False)
-    else:
-        monkeypatch.setenv("LV_PREFILL_CFG", cfg)
+    monkeypatch.setitem(ops.DEFAULT_KERNEL, "prefill", {"auto": "auto", "0": "w4", "1": "w8", "2": "pp", "4": "w64"}[cfg])
     case = make_prefill_case(4000 + seed, lens_q, lens_k, Hq, Hkv, block_size=block, paged=paged)
     d = to_dev(case, gpu)
     out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],

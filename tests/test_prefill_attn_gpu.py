@@ -13,10 +13,9 @@ TOL = 2e-2
 def kernel_config(request, monkeypatch):
     """Every case runs under the library's own choice of kernel and under each forced one:
     0 = 4 waves / 128-row tiles, 1 = 8 waves / 256-row tiles, 2 = the phase-locked 8-wave kernel."""
-    if request.param == "auto":
-        monkeypatch.delenv("LV_PREFILL_CFG", raising=False)
-    else:
-        monkeypatch.setenv("LV_PREFILL_CFG", request.param)
+    from light_vllm_amd import ops
+    monkeypatch.setitem(ops.DEFAULT_KERNEL, "prefill",
+                        {"auto": "auto", "0": "w4", "1": "w8", "2": "pp", "4": "w64"}[request.param])
     return request.param
 
 

@@ -18,7 +18,7 @@ def test_decode_spiky(gpu, monkeypatch, seed):
     lens = [int(torch.randint(1, 3001, (), generator=g)) for _ in range(B)]
     ns = [0, 1, 2, 5][int(torch.randint(0, 4, (), generator=g))]
     if Hq // Hkv in (1, 2, 4, 8):
-        monkeypatch.setenv("LV_DECODE_MFMA", str(seed % 2))
+        monkeypatch.setitem(ops.DEFAULT_KERNEL, "decode", ["valu", "mfma"][seed % 2])
     case = make_decode_case(9500 + seed, lens, Hq, Hkv)
     case["q"] = (case["q"].float() * [1.0, 3.0, 6.0][seed % 3]).to(torch.bfloat16)
     if seed % 2:

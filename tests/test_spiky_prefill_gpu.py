@@ -24,7 +24,7 @@ def test_prefill_long_spiky(gpu, monkeypatch, seed, cfg):
     paged = seed % 2 == 1
     block = [64, 256][int(torch.randint(0, 2, (), generator=g))]
     lens_k = [lq + (block * int(torch.randint(0, 4, (), generator=g)) if paged else 0) for lq in lens_q]
-    monkeypatch.setenv("LV_PREFILL_CFG", cfg)
+    monkeypatch.setitem(ops.DEFAULT_KERNEL, "prefill", {"0": "w4", "1": "w8", "2": "pp", "4": "w64"}[cfg])
     case = make_prefill_case(8000 + seed, lens_q, lens_k, Hq, Hkv, block_size=block, paged=paged)
     case["q"] = (case["q"].float() * (3.0 if seed < 4 else 6.0)).to(torch.bfloat16)
     if not paged:

@@ -112,7 +112,10 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="decode")
+    ap.add_argument("--decode-kernel", default="auto", choices=list(ops.DECODE_KERNELS))
+    ap.add_argument("--prefill-kernel", default="auto", choices=list(ops.PREFILL_KERNELS))
     args = ap.parse_args()
+    ops.DEFAULT_KERNEL.update(decode=args.decode_kernel, prefill=args.prefill_kernel)
     rows = []
     if args.what in ("decode", "all"):
         for (Hq, Hkv) in [(16, 8), (32, 8), (64, 8)]:

@@ -1,7 +1,8 @@
 // Diagnostic harness (not shipped): builds the prefill kernel with s_memtime stamps and prints the
 // share of wave time spent in each loop segment. Build and run:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLV_STAMPS -Iinclude -Ilight_vllm_amd/csrc \
-//         tools/prefill_diag.hip -o tools/prefill_diag && tools/prefill_diag
+//         tools/prefill_diag.hip -o tools/prefill_diag && tools/prefill_diag [seqlen [kernel_hint]]
+// kernel_hint: an LV_PREFILL_KERNEL_* value (0 = the library's choice, 3 = phase-locked, 5 = 64 rows per wave).
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -28,6 +29,7 @@ static uint16_t rnd_bf16(uint64_t& s) {
 
 int main(int argc, char** argv) {
   const int B = 4, L = argc > 1 ? atoi(argv[1]) : 4096, Hq = 32, Hkv = 8, D = 128;
+  const int hint = argc > 2 ? atoi(argv[2]) : LV_PREFILL_KERNEL_AUTO;
   const size_t nq = (size_t)B * L * Hq * D, nk = (size_t)B * L * Hkv * D;
   std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
   uint64_t seed = 1;
@@ -54,6 +56,7 @@ int main(int argc, char** argv) {
   p.q_stride0 = p.o_stride0 = Hq * D; p.k_stride0 = p.v_stride0 = Hkv * D;
   p.cu_q = dcu; p.cu_k = dcu; p.block_table = nullptr; p.bt_stride = 0; p.block_size = 0;
   p.batch = B; p.max_seqlen_q = L; p.num_heads = Hq; p.num_kv_heads = Hkv;
+  p.kernel_hint = hint;
   p.scale_log2e = 0.08838834764f * 1.4426950408889634f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> times;
@@ -81,9 +84,9 @@ int main(int argc, char** argv) {
                               "barrier after C_PV", "L_V: K publish + loads", "L_V: V reads (+wait)", "L_K: V publish + loads", "L_K: K reads (+wait)", "-", "-", "-", "-"};
   const char* names_w64[16] = {"barrier", "pending rescale + DMA wait", "-", "tile bases", "QK gaps 17-31",
                                "PV gaps 17-31", "PV: V reads + gap 0 (settle, mask)", "-", "PV gaps 1-2 (decisions)", "QK: K reads + gap 0", "QK gaps 1-16 (4 DMA)", "PV gaps 3-16", "-", "-", "-", "-"};
-  const char* cfg = getenv("LV_PREFILL_CFG");
-  if (cfg && atoi(cfg) == 2) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
-  if (cfg && atoi(cfg) == 4) { for (int i = 0; i < 16; ++i) names[i] = names_w64[i]; tot -= seg[14]; seg[14] = 0; }
+  const bool is_pp = hint == LV_PREFILL_KERNEL_PP || (hint == LV_PREFILL_KERNEL_AUTO && L >= 2048);
+  if (is_pp) for (int i = 0; i < 16; ++i) names[i] = names_pp[i];
+  if (hint == LV_PREFILL_KERNEL_W64) { for (int i = 0; i < 16; ++i) names[i] = names_w64[i]; tot -= seg[14]; seg[14] = 0; }
   if (seg[13] > 0) printf("in-kernel clock: %.0f MHz (shader ticks per 100 MHz reference tick, averaged over waves)\n", 100.0 * seg[12] / seg[13]);
   tot -= seg[12] + seg[13]; seg[12] = seg[13] = 0;
   tot -= seg[15];

@@ -4,8 +4,8 @@
 #   for a in 0 512 640 8832 704; do hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLV_STAMPS \
 #     -DLV_ABL=$a -Iinclude -Ilight_vllm_amd/csrc tools/prefill_diag.hip -o tools/prefill_abl$a; done
 # then run this script on the GPU: per-cluster cycles per (wave, tile) for every variant.
-export LV_PREFILL_CFG=${LV_PREFILL_CFG:-2}
+HINT=${LV_PREFILL_HINT:-3}   # LV_PREFILL_KERNEL_PP
 for a in ${ABL_MASKS:-0 512 640 8832 704}; do
   echo "== ABL $a"
-  timeout -k 10 60 tools/prefill_abl$a 4096 | grep -E "launches|C_QK|C_PV|L_K:|L_V|total" || exit 1
+  timeout -k 10 60 tools/prefill_abl$a 4096 $HINT | grep -E "launches|C_QK|C_PV|L_K:|L_V|total" || exit 1
 done
