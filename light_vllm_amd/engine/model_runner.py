@@ -19,6 +19,7 @@ MI355X:
 from __future__ import annotations
 
 import pickle
+import re
 from multiprocessing.shared_memory import SharedMemory
 
 import torch
@@ -32,7 +33,11 @@ from ..utils.context import get_context, reset_context, set_context
 from ..utils.loader import load_model, load_random, load_random_on_device
 from .sequence import Sequence
 
-_SHM_NAME = "lightvllm_amd"
+
+def _shm_name(init_method: str) -> str:
+    """Name of the step-RPC segment, derived from the rendezvous address so that two engines on
+    one host (different ports) never share or unlink each other's segment."""
+    return "lightvllm_amd_" + re.sub(r"[^0-9A-Za-z]+", "_", init_method).strip("_")
 
 
 class ModelRunner:
@@ -85,18 +90,21 @@ class ModelRunner:
             torch.set_default_dtype(default_dtype)
 
         if self.world_size > 1:
+            name = _shm_name(config.dist_init_method)
             if rank == 0:
                 try:
-                    self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
-                except FileExistsError:     # left behind by a run that died: replace it
-                    stale = SharedMemory(name=_SHM_NAME)
+                    self.shm = SharedMemory(name=name, create=True, size=2 ** 20)
+                except FileExistsError:
+                    # Same rendezvous address, which this process group has just bound: the segment
+                    # can only be left over from a run that died. Replace it.
+                    stale = SharedMemory(name=name)
                     stale.close()
                     stale.unlink()
-                    self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
+                    self.shm = SharedMemory(name=name, create=True, size=2 ** 20)
                 dist.barrier()
             else:
                 dist.barrier()
-                self.shm = SharedMemory(name=_SHM_NAME)
+                self.shm = SharedMemory(name=name)
                 self.loop()
 
     # ------------------------------------------------------------------ lifecycle / step RPC
@@ -178,6 +186,10 @@ class ModelRunner:
             current = stats["allocated_bytes.all.current"]
             available = int(total * cfg.gpu_memory_utilization) - used - peak + current
             num_blocks = available // block_bytes
+            # what the count was computed from, kept for logs and tests
+            self.kv_sizing = dict(total=total, used=used, peak=peak, current=current, block_bytes=block_bytes,
+                                  utilization=cfg.gpu_memory_utilization, blocks_from_memory=int(num_blocks),
+                                  cap=cfg.num_kvcache_blocks)
             if cfg.num_kvcache_blocks > 0:
                 num_blocks = min(num_blocks, cfg.num_kvcache_blocks)
         else:
@@ -198,6 +210,14 @@ class ModelRunner:
         assert layer_id == hf.num_hidden_layers
 
     # ------------------------------------------------------------------ step inputs
+    def _check_positions(self, last_position: int) -> None:
+        """Positions index the rotary table (max_position_embeddings rows). The fused kernel clamps
+        instead of faulting, so the range is enforced here, where the lengths are known."""
+        limit = self.config.hf_config.max_position_embeddings
+        if last_position >= limit:
+            raise IndexError(f"position {last_position} is outside the rotary table of {limit} rows "
+                             "(sequence longer than max_position_embeddings)")
+
     def _to_device(self, values, dtype) -> torch.Tensor:
         if self.on_gpu:
             return torch.tensor(values, dtype=dtype, pin_memory=True).cuda(self.device, non_blocking=True)
@@ -229,6 +249,7 @@ class ModelRunner:
                 start = seq.block_table[i] * bs
                 count = bs if i != last else seq.last_block_num_tokens
                 slot_mapping.extend(range(start, start + count))
+        self._check_positions(max_k - 1)
         block_tables = self.prepare_block_tables(seqs) if cu_k[-1] > cu_q[-1] else None
         input_ids = self._to_device(input_ids, torch.int64)
         positions = self._to_device(positions, torch.int64)
@@ -244,6 +265,7 @@ class ModelRunner:
         positions = [len(seq) for seq in seqs]
         context_lens = context_lens_host = [len(seq) for seq in seqs]
         slot_mapping = [seq.block_table[-1] * bs + seq.last_block_num_tokens - 1 for seq in seqs]
+        self._check_positions(max(positions))
         input_ids = self._to_device(input_ids, torch.int64)
         positions = self._to_device(positions, torch.int64)
         slot_mapping = self._to_device(slot_mapping, torch.int32)
@@ -325,8 +347,10 @@ class ModelRunner:
         hq = hf.num_attention_heads // self.world_size
         hkv = hf.num_key_value_heads // self.world_size
         head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        # every batch size the runner can see, the eager overflow above the largest bucket included,
+        # so the workspace the graphs were captured with is never outgrown
         need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks, self.block_size))
-                   for b in self.graph_bs)
+                   for b in self.graph_bs + [cfg.max_num_seqs])
         ops.reserve_decode_workspace(dev, need)
 
         for bs in reversed(self.graph_bs):

@@ -33,6 +33,7 @@ class Scheduler:
 
     def preempt(self, seq: Sequence) -> None:
         seq.status = SequenceStatus.WAITING
+        seq.needs_prefill = True          # recomputed from all its tokens when it is scheduled again
         self.block_manager.deallocate(seq)
         self.waiting.appendleft(seq)
 
@@ -72,6 +73,7 @@ class Scheduler:
     def postprocess(self, seqs: list[Sequence], token_ids: list[int]) -> None:
         for seq, token_id in zip(seqs, token_ids):
             seq.append_token(token_id)
+            seq.needs_prefill = False
             if (not seq.ignore_eos and token_id == self.eos) or seq.num_completion_tokens == seq.max_tokens:
                 seq.status = SequenceStatus.FINISHED
                 self.block_manager.deallocate(seq)

@@ -42,6 +42,9 @@ class Sequence:
         self.temperature = sampling_params.temperature
         self.max_tokens = sampling_params.max_tokens
         self.ignore_eos = sampling_params.ignore_eos
+        # True until the sequence's KV is in the cache: at creation and again after a preemption
+        # (the scheduler sets it). Decides what the step RPC ships to the workers, see __getstate__.
+        self.needs_prefill = True
 
     def __len__(self) -> int:
         return self.num_tokens
@@ -94,14 +97,20 @@ class Sequence:
         self.last_token = token_id
         self.num_tokens += 1
 
-    # Workers only need the full prompt once (for prefill); afterwards the last token is enough.
+    # Workers need every token of a sequence that is about to be prefilled: the first time, and
+    # again after a preemption, when the prompt is recomputed together with the tokens generated
+    # so far. (The reference ships the full list only while nothing has been generated,
+    # sequence.py:145-174, so its workers get a one-token list for a preempted sequence.) For a
+    # decode step the last token is enough.
     def __getstate__(self):
-        tail = self.token_ids if self.num_completion_tokens == 0 else self.last_token
-        return (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table, tail)
+        tail = self.token_ids if self.needs_prefill else self.last_token
+        return (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table,
+                self.needs_prefill, tail)
 
     def __setstate__(self, state):
-        self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table = state[:-1]
-        if self.num_completion_tokens == 0:
+        (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.block_table,
+         self.needs_prefill) = state[:-1]
+        if self.needs_prefill:
             self.token_ids = state[-1]
             self.last_token = self.token_ids[-1]
         else:

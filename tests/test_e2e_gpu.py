@@ -134,50 +134,79 @@ def test_long_prompt_scenario_gqa4(gpu, enforce_eager):
     assert len(soft) <= 3, f"too many tie flips: {soft}"
 
 
+def _stepwise_logits(prompts, params, eager, forced=None, max_num_seqs=16):
+    """Drives scheduler + runner step by step; returns (per-step logits on CPU, per-step tokens,
+    per-step (is_prefill, batch size)). With `forced`, continues from those tokens instead of its own."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from light_vllm_amd.engine.sequence import Sequence
+    from light_vllm_amd.utils.context import reset_context
+    from tests._e2e import gqa4_config
+    cfg = Config(None, hf_config=gqa4_config(4), num_kvcache_blocks=64, max_num_seqs=max_num_seqs,
+                 enforce_eager=eager, random_seed=3)
+    runner, sch = ModelRunner(cfg, 0, []), Scheduler(cfg)
+    for p, sp in zip(prompts, params):
+        sch.add(Sequence(p, sp))
+    logits_per_step, tokens_per_step, kinds = [], [], []
+    step = 0
+    while not sch.is_finished():
+        batch, is_prefill = sch.schedule()
+        ids, pos = runner.prepare_prefill(batch) if is_prefill else runner.prepare_decode(batch)
+        logits = runner.run_model(ids, pos, is_prefill).float()
+        reset_context()
+        toks = logits.argmax(-1).tolist() if forced is None else forced[step]
+        logits_per_step.append(logits.cpu())
+        tokens_per_step.append(toks)
+        kinds.append((is_prefill, len(batch)))
+        sch.postprocess(batch, toks)
+        step += 1
+    runner.exit()
+    return logits_per_step, tokens_per_step, kinds
+
+
 def test_graph_padding_rows_match_eager(gpu):
     """Five sequences of different lengths decode in the 8-row graph bucket: three padding rows
     (slot -1, context length 0, their own index in the launch order) ride along. Logits of every
     step must match an eager runner fed the same tokens to within bf16 noise (the two differ in
     split count only)."""
-    from light_vllm_amd.config import Config
-    from light_vllm_amd.engine.model_runner import ModelRunner
-    from light_vllm_amd.engine.scheduler import Scheduler
-    from light_vllm_amd.engine.sequence import Sequence
     from light_vllm_amd.sampling_params import SamplingParams
-    from light_vllm_amd.utils.context import reset_context
-    from tests._e2e import gqa4_config
     g = torch.Generator().manual_seed(11)
     prompts = [torch.randint(0, 151936, (n,), generator=g).tolist() for n in (100, 257, 600, 31, 512)]
-    sp = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
-    runs = []
-    forced = None
-    for eager in (True, False):
-        cfg = Config(None, hf_config=gqa4_config(4), num_kvcache_blocks=64, max_num_seqs=16, enforce_eager=eager,
-                     random_seed=3)
-        runner, sch = ModelRunner(cfg, 0, []), Scheduler(cfg)
-        seqs = [Sequence(p, sp) for p in prompts]
-        for s in seqs:
-            sch.add(s)
-        logits_per_step, tokens_per_step = [], []
-        step = 0
-        while not sch.is_finished():
-            batch, is_prefill = sch.schedule()
-            ids, pos = runner.prepare_prefill(batch) if is_prefill else runner.prepare_decode(batch)
-            logits = runner.run_model(ids, pos, is_prefill).float()
-            reset_context()
-            toks = logits.argmax(-1).tolist() if forced is None else forced[step]
-            logits_per_step.append(logits.cpu())
-            tokens_per_step.append(toks)
-            sch.postprocess(batch, toks)
-            step += 1
-        runner.exit()
-        runs.append(logits_per_step)
-        if forced is None:
-            forced = tokens_per_step
-    assert len(runs[0]) == len(runs[1]) == 8
-    for a, b in zip(runs[0], runs[1]):
+    params = [SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)] * 5
+    eager, forced, _ = _stepwise_logits(prompts, params, True)
+    graph, _, _ = _stepwise_logits(prompts, params, False, forced)
+    assert len(eager) == len(graph) == 8
+    for a, b in zip(eager, graph):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 0.06
+
+
+def test_eager_overflow_batch_keeps_graph_workspace(gpu):
+    """max_num_seqs 20 is not a multiple of 16: decode batches of 17-20 run eagerly above the
+    largest graph bucket and need a larger split-KV workspace than any captured graph. Growing
+    the workspace then must not free the buffer the graphs were captured with: after four
+    sequences finish, the 16-row graph replays, and its logits must still match an all-eager run
+    (a freed workspace shows up as garbage in the merged attention output)."""
+    from light_vllm_amd import ops
+    from light_vllm_amd.sampling_params import SamplingParams
+    g = torch.Generator().manual_seed(12)
+    prompts = [torch.randint(0, 151936, (int(n),), generator=g).tolist()
+               for n in torch.randint(20, 700, (20,), generator=g)]
+    params = [SamplingParams(temperature=0.0, max_tokens=3 if i % 5 == 0 else 7, ignore_eos=True) for i in range(20)]
+    eager, forced, kinds = _stepwise_logits(prompts, params, True, max_num_seqs=20)
+    ops._WORKSPACE.clear()                      # the graph run sizes the workspace on its own
+    graph, _, kinds_g = _stepwise_logits(prompts, params, False, forced, max_num_seqs=20)
+    assert kinds == kinds_g
+    decode_sizes = [n for is_prefill, n in kinds if not is_prefill]
+    assert 20 in decode_sizes and 16 in decode_sizes and decode_sizes.index(20) < decode_sizes.index(16)
+    for a, b in zip(eager, graph):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 0.06
+    # a later, larger direct call still must not drop a buffer that launches have used
+    before = ops._WORKSPACE[gpu.index or 0]
+    ops.reserve_decode_workspace(gpu, before.numel() + (1 << 20))
+    assert any(t is before for t in ops._RETIRED)
 
 
 def test_preemption_and_recompute_on_gpu(gpu):

@@ -92,22 +92,24 @@ def test_tp_layers_world2(tmp_path):
 
 
 # ------------------------------------------------------------------ engine level
-def _prompts():
+def _prompts(lens=(300, 40, 257)):
     g = torch.Generator().manual_seed(7)
-    return [torch.randint(0, 512, (n,), generator=g).tolist() for n in (300, 40, 257)]
+    return [torch.randint(0, 512, (n,), generator=g).tolist() for n in lens]
 
 
-def _generate(runner, cfg, max_tokens):
+def _generate(runner, cfg, max_tokens, lens=(300, 40, 257), trace=None):
     from light_vllm_amd.engine.scheduler import Scheduler
     from light_vllm_amd.engine.sequence import Sequence
     from light_vllm_amd.sampling_params import SamplingParams
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)
-    seqs = [Sequence(p, sp) for p in _prompts()]
+    seqs = [Sequence(p, sp) for p in _prompts(lens)]
     for s in seqs:
         sch.add(s)
     while not sch.is_finished():
         batch, is_prefill = sch.schedule()
+        if trace is not None:
+            trace.append((is_prefill, [(seqs.index(s), s.num_completion_tokens) for s in batch]))
         toks = runner.call("run", batch, is_prefill)
         sch.postprocess(batch, toks)
     return [list(s.completion_token_ids) for s in seqs]
@@ -150,3 +152,70 @@ def test_tp2_engine_matches_tp1(tmp_path):
         runner = ModelRunner(cfg, 0, [])
         tp1 = _generate(runner, cfg, max_tokens=6)
     assert tp2 == tp1
+
+
+# ------------------------------------------------------------------ preemption under TP
+# Three one-block prompts in a three-block pool: when the first sequence crosses its block boundary
+# nothing is free, the scheduler preempts the last running sequence, and that sequence is later
+# prefilled again together with the tokens it had generated. The worker rank must then receive all
+# of those tokens over the step RPC (a one-token list would shape-error in its prefill and leave
+# rank 0 waiting in the next all-reduce).
+_PREEMPT_LENS = (250, 40, 250)
+
+
+def _preempt_worker(rank, world, port, event, out_dir):
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from tests._cpu_kernels import cpu_kernels
+    cfg = Config(None, hf_config=_tiny_config(), device="cpu", tensor_parallel_size=world, num_kvcache_blocks=3,
+                 max_model_len=512, max_num_batched_tokens=1024, random_seed=3,
+                 dist_init_method=f"tcp://127.0.0.1:{port}")
+    with cpu_kernels():
+        if rank == 0:
+            runner = ModelRunner(cfg, 0, [event])
+            trace = []
+            out = _generate(runner, cfg, max_tokens=10, lens=_PREEMPT_LENS, trace=trace)
+            runner.call("exit")
+            torch.save((out, trace), os.path.join(out_dir, "tp2_preempt.pt"))
+        else:
+            ModelRunner(cfg, rank, event)
+
+
+def test_tp2_engine_preemption_reprefills_generated_tokens(tmp_path):
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from tests._cpu_kernels import cpu_kernels
+    ctx = mp.get_context("spawn")
+    event = ctx.Event()
+    port = _free_port()
+    procs = [ctx.Process(target=_preempt_worker, args=(r, 2, port, event, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    tp2, trace = torch.load(os.path.join(str(tmp_path), "tp2_preempt.pt"))
+    # a sequence that had already generated tokens went through a prefill step again
+    assert any(is_prefill and any(done > 0 for _, done in batch) for is_prefill, batch in trace), trace
+    cfg = Config(None, hf_config=_tiny_config(), device="cpu", num_kvcache_blocks=3, max_model_len=512,
+                 max_num_batched_tokens=1024, random_seed=3)
+    with cpu_kernels():
+        runner = ModelRunner(cfg, 0, [])
+        tp1 = _generate(runner, cfg, max_tokens=10, lens=_PREEMPT_LENS)
+    assert tp2 == tp1
+
+
+def test_sequence_pickle_ships_all_tokens_until_prefilled():
+    import pickle
+    from light_vllm_amd.engine.sequence import Sequence
+    s = Sequence([5, 6, 7])
+    assert pickle.loads(pickle.dumps(s)).token_ids == [5, 6, 7]
+    s.append_token(8)
+    s.needs_prefill = False                      # what Scheduler.postprocess does
+    w = pickle.loads(pickle.dumps(s))
+    assert w.token_ids == [8] and w.last_token == 8 and len(w) == 4
+    s.needs_prefill = True                       # what Scheduler.preempt does
+    w = pickle.loads(pickle.dumps(s))
+    assert w.token_ids == [5, 6, 7, 8] and len(w) == 4
