@@ -239,6 +239,33 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    void* workspace, size_t workspace_bytes, int num_splits,
                    const int32_t* seq_order, int kernel_hint, lv_stream_t stream);
 
+/*
+ * lv_decode_attn for callers that cannot allocate device memory or carry a workspace (code under
+ * hipGraph capture, tight serving loops, harnesses that forbid hipMalloc). No counterpart in the
+ * reference: it is the same function as lv_decode_attn (same arguments, kernels and results, bit for
+ * bit), but the split-KV partials go to a device array built into the library instead of a caller
+ * workspace, and the call allocates nothing.
+ *
+ *   - The array is LV_DECODE_STATIC_SCRATCH_BYTES large on every GPU the library runs on, for the
+ *     life of the process. A call whose (batch, num_heads, num_splits) needs more
+ *     (lv_decode_workspace_bytes) returns LV_ERR_WORKSPACE and launches nothing; every split count
+ *     lv_decode_num_splits returns fits.
+ *   - Every call on a GPU shares that GPU's array: calls on one stream are ordered and safe (each
+ *     call's merge pass reads only what its own split pass wrote); calls that overlap on one GPU
+ *     (two streams, two threads) race. Use lv_decode_attn with separate workspaces for those.
+ *   - The array's address is looked up on the first call on each device; make that first call
+ *     outside stream capture.
+ */
+#define LV_DECODE_STATIC_SCRATCH_BYTES (17u << 20)
+int lv_decode_attn_static(const void* q, const void* k_cache, const void* v_cache, void* o,
+                          int64_t q_stride0, int64_t o_stride0,
+                          const int32_t* context_lens,
+                          const int32_t* block_table, int block_table_stride,
+                          int batch, int max_blocks_per_seq, int block_size,
+                          int num_heads, int num_kv_heads, int head_dim, float scale,
+                          int num_splits, const int32_t* seq_order, int kernel_hint,
+                          lv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

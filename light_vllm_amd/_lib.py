@@ -35,6 +35,9 @@ SIGNATURES = {
     "lv_decode_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_void_p, c_size_t, c_int, c_void_p, c_int, c_void_p]),
+    "lv_decode_attn_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "lv_kernels.h"
 
 namespace lv {
@@ -54,6 +56,46 @@ static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq,
   if (n > kMaxSplits) n = kMaxSplits;
   if (n * units > kMaxWorkgroups) n = kMaxWorkgroups / units;
   return n < 1 ? 1 : static_cast<int>(n);
+}
+
+}  // namespace lv
+
+// Split-KV scratch of lv_decode_attn_static: a device array of the code object, so that entry
+// point never allocates. 17 MiB holds the partials of every split count the library's own
+// heuristic picks (batch x kv heads x splits <= 4096 workgroups, <= 8 query heads each:
+// 32768 x (128 + 2) floats = 16.25 MiB). Every GPU the library runs on holds its own copy at its
+// own address until the process ends. In host code the array's NAME is only a handle for
+// hipGetSymbolAddress; kernels and memsets take the resolved per-device pointer.
+static __device__ __align__(256) unsigned char scratch[LV_DECODE_STATIC_SCRATCH_BYTES];
+
+namespace lv {
+
+constexpr size_t kStaticScratchBytes = LV_DECODE_STATIC_SCRATCH_BYTES;
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on the current device; resolved on the first call per device
+// (with that device current) and kept. nullptr + recorded message on failure.
+static void* static_scratch_ptr() {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    fail(LV_ERR_LAUNCH, "decode_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      fail(LV_ERR_LAUNCH, "decode_static: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+           hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  return g_scratch_ptr[dev];
 }
 
 }  // namespace lv
@@ -249,12 +291,14 @@ size_t lv_decode_workspace_bytes(int batch, int num_heads, int head_dim, int num
 
 }  // extern "C"
 
+// Shared body of lv_decode_attn and lv_decode_attn_static. `static_scratch`: the workspace is the
+// library's own device array, resolved (once per device) only when the call needs splits.
 static int decode_entry(const void* q, const void* k_cache, const void* v_cache, void* o,
                         int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
                         const int32_t* block_table, int block_table_stride, int batch,
                         int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
                         int head_dim, float scale, void* workspace, size_t workspace_bytes,
-                        int num_splits, const int32_t* seq_order,
+                        bool static_scratch, int num_splits, const int32_t* seq_order,
                         int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_blocks_per_seq < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_splits < 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: negative size");
@@ -297,6 +341,16 @@ static int decode_entry(const void* q, const void* k_cache, const void* v_cache,
   p.ws_ml = nullptr;
   if (nsplit > 1) {
     const size_t need = lv_decode_workspace_bytes(batch, num_heads, head_dim, nsplit);
+    if (static_scratch) {
+      if (need > kStaticScratchBytes)
+        return fail(LV_ERR_WORKSPACE,
+                    "decode_static: batch %d x %d heads x %d splits needs %zu B of scratch, the built-in "
+                    "array holds %zu B; use lv_decode_attn with a caller workspace",
+                    batch, num_heads, nsplit, need, kStaticScratchBytes);
+      workspace = static_scratch_ptr();
+      if (!workspace) return LV_ERR_LAUNCH;   // message recorded by static_scratch_ptr
+      workspace_bytes = kStaticScratchBytes;
+    }
     if (!workspace || workspace_bytes < need || !aligned16(workspace))
       return fail(LV_ERR_WORKSPACE, "decode: workspace %zu B < %zu B needed for %d splits (or misaligned)",
                   workspace_bytes, need, nsplit);
@@ -329,8 +383,20 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    int num_splits, const int32_t* seq_order, int kernel_hint, lv_stream_t stream) {
   return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
                       block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
-                      num_kv_heads, head_dim, scale, workspace, workspace_bytes, num_splits,
+                      num_kv_heads, head_dim, scale, workspace, workspace_bytes, false, num_splits,
                       seq_order, kernel_hint, stream);
+}
+
+int lv_decode_attn_static(const void* q, const void* k_cache, const void* v_cache, void* o,
+                          int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
+                          const int32_t* block_table, int block_table_stride, int batch,
+                          int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
+                          int head_dim, float scale, int num_splits, const int32_t* seq_order,
+                          int kernel_hint, lv_stream_t stream) {
+  return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
+                      block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
+                      num_kv_heads, head_dim, scale, nullptr, 0, true, num_splits, seq_order,
+                      kernel_hint, stream);
 }
 
 }  // extern "C"

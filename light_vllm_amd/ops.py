@@ -171,7 +171,8 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                      context_lens: torch.Tensor, block_table: torch.Tensor, softmax_scale: float,
                      num_splits: int = 0, out: Optional[torch.Tensor] = None,
                      seq_order: Optional[torch.Tensor] = None, kernel: Optional[str] = None,
-                     workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     workspace: Optional[torch.Tensor] = None,
+                     static_scratch: bool = False) -> torch.Tensor:
     """One query token per sequence over the paged cache.
 
     q: [B, Hq, D]; caches [num_blocks, block_size, Hkv, D] contiguous; context_lens int32 [B]
@@ -182,6 +183,8 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     the default order); the result does not depend on it.
     kernel: a key of DECODE_KERNELS to force one kernel (default: DEFAULT_KERNEL["decode"]).
     workspace: caller-owned uint8 scratch for the split partials (default: the per-device one).
+    static_scratch: use lv_decode_attn_static (the library's built-in device array holds the
+    partials, nothing is allocated here or there; `out` must then be given).
     """
     dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
     B, Hq, D = q.shape
@@ -206,6 +209,16 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
         return out
     lib = _lib.load()
     nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks, block_size)
+    if static_scratch:
+        with torch.cuda.device(dev):
+            rc = lib.lv_decode_attn_static(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                                           q.stride(0), out.stride(0), context_lens.data_ptr(),
+                                           block_table.data_ptr(), block_table.stride(0), B, max_blocks,
+                                           block_size, Hq, Hkv, D, float(softmax_scale), nsplit,
+                                           seq_order.data_ptr() if seq_order is not None else None,
+                                           _decode_hint(kernel, Hq // Hkv), _stream_ptr(dev))
+        _lib.check(rc, "lv_decode_attn_static")
+        return out
     need = lib.lv_decode_workspace_bytes(B, Hq, D, nsplit)
     if workspace is not None:
         assert workspace.is_cuda and workspace.device == dev and workspace.is_contiguous()

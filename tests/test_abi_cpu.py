@@ -4,20 +4,22 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "lv_attention.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("lv_attention.h",)]
 
 
 def declared_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(lv_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+        names.update(re.findall(r"\b(lv_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
-        "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn"])
+        "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static"])
 
 
 def test_library_exports_every_declared_symbol():
