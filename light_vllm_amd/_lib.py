@@ -1,4 +1,5 @@
-"""ctypes binding of liblvattn.so, the C-ABI library declared in include/lv_attention.h.
+"""ctypes binding of liblvattn.so, the C-ABI library declared in include/lv_attention.h and
+include/lv_comm.h.
 
 The library is the only compute path: if it is missing, or a call fails, a RuntimeError is raised.
 There is no CPU or PyTorch fallback here.
@@ -7,14 +8,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvattn.so")
 
 ABI_VERSION = 5
 
-# name -> (restype, argtypes); must list every symbol include/lv_attention.h declares.
+# name -> (restype, argtypes); must list every symbol include/*.h declares.
 SIGNATURES = {
     "lv_abi_version": (c_int, []),
     "lv_error_string": (c_char_p, [c_int]),
@@ -38,6 +39,12 @@ SIGNATURES = {
     "lv_decode_attn_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p, c_int, c_void_p]),
+    "lv_comm_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "lv_comm_get_handle": (c_int, [c_void_p, c_void_p]),
+    "lv_comm_connect": (c_int, [c_void_p, c_char_p]),
+    "lv_comm_all_reduce": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lv_comm_failed": (c_int, [c_void_p]),
+    "lv_comm_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,100 @@
+"""Direct small-message all-reduce between the ranks of one node (include/lv_comm.h): the
+transport the tensor-parallel layers use for decode-sized sums instead of torch.distributed
+(reference call sites: dist.all_reduce at lightvllm/layers/linear.py:388-389 and
+layers/embed_head.py:112). One communicator per process, created after the process group exists;
+the HIP IPC handles of the ranks' buffers travel through that group (all_gather_object), the
+data never does.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+MAX_BYTES = 4 << 20          # LV_COMM_MAX_BYTES
+HANDLE_BYTES = 64            # LV_COMM_HANDLE_BYTES
+
+
+class DirectAllReduce:
+    """This rank's end of an lv_comm communicator on `device`."""
+
+    def __init__(self, device: torch.device, rank: int, world_size: int, timeout_ms: int = 0, group=None):
+        self.device = torch.device(device)
+        self.rank, self.world_size = rank, world_size
+        self._lib = _lib.load()
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.lv_comm_create(rank, world_size, timeout_ms, ctypes.byref(self._comm)), "lv_comm_create")
+            mine = ctypes.create_string_buffer(HANDLE_BYTES)
+            _lib.check(self._lib.lv_comm_get_handle(self._comm, mine), "lv_comm_get_handle")
+            blobs = [None] * world_size
+            dist.all_gather_object(blobs, bytes(mine.raw), group=group)
+            assert all(isinstance(b, bytes) and len(b) == HANDLE_BYTES for b in blobs)
+            _lib.check(self._lib.lv_comm_connect(self._comm, b"".join(blobs)), "lv_comm_connect")
+        dist.barrier(group=group)          # every rank has mapped every peer before the first use
+
+    def usable(self, t: torch.Tensor) -> bool:
+        nbytes = t.numel() * t.element_size()
+        return (self._comm is not None and t.is_cuda and t.device == self.device and t.dtype == torch.bfloat16
+                and t.is_contiguous() and 0 < nbytes <= MAX_BYTES and nbytes % 16 == 0 and t.data_ptr() % 16 == 0)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place bf16 sum over the ranks (fp32 accumulation in rank order, identical bits on
+        every rank). Stream-ordered on torch's current stream; capturable into a hipGraph."""
+        assert self.usable(t), "direct all-reduce: contiguous bf16 GPU tensor of at most 4 MiB, 16-byte multiple"
+        with torch.cuda.device(self.device):
+            rc = self._lib.lv_comm_all_reduce(self._comm, t.data_ptr(), t.numel(),
+                                              torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "lv_comm_all_reduce")
+        return t
+
+    def failed(self) -> bool:
+        return self._comm is None or bool(self._lib.lv_comm_failed(self._comm))
+
+    def close(self) -> None:
+        if self._comm is not None:
+            with torch.cuda.device(self.device):
+                self._lib.lv_comm_destroy(self._comm)
+            self._comm = None
+
+
+def create_for_group(device: torch.device, timeout_ms: int = 0, group=None) -> Optional[DirectAllReduce]:
+    """Collective over `group`: every rank tries to build its end; the communicator is kept only if
+    every rank succeeded (IPC can be unavailable, e.g. ranks in different containers), otherwise all
+    ranks drop it together and the callers stay on RCCL. Returns None then."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    comm, err = None, ""
+    ok = False
+    if 2 <= world <= 8:
+        try:
+            comm = DirectAllReduce(device, rank, world, timeout_ms, group)
+            ok = True
+        except Exception as exc:      # noqa: BLE001 - any failure means "not available on this rank"
+            err = repr(exc)
+    flags = [None] * world
+    dist.all_gather_object(flags, (ok, err), group=group)
+    if all(f[0] for f in flags):
+        return comm
+    if comm is not None:
+        comm.close()
+    if rank == 0:
+        print("direct all-reduce unavailable, staying on torch.distributed:",
+              "; ".join(f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0]), flush=True)
+    return None
+
+
+_ACTIVE: Optional[DirectAllReduce] = None
+
+
+def install(comm: Optional[DirectAllReduce]) -> None:
+    """Make `comm` the transport layers.tp.all_reduce uses for messages it can take (None: none)."""
+    global _ACTIVE
+    _ACTIVE = comm
+
+
+def active() -> Optional[DirectAllReduce]:
+    return _ACTIVE

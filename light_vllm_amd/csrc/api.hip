@@ -113,6 +113,7 @@ const char* lv_error_string(int code) {
     case LV_ERR_UNSUPPORTED: return "unsupported configuration";
     case LV_ERR_LAUNCH: return "kernel launch failed";
     case LV_ERR_WORKSPACE: return "workspace too small or misaligned";
+    case -5: return "communicator failure";
     default: return "unknown error";
   }
 }

@@ -1,0 +1,294 @@
+// Direct small-message all-reduce between the GPUs (or processes) of one node, declared in
+// include/lv_comm.h. It serves the decode-sized sum all-reduces of the tensor-parallel layers
+// (reference: dist.all_reduce at lightvllm/layers/linear.py:388-389 and layers/embed_head.py:112).
+//
+// Every rank owns one allocation of uncached device memory that all peers map through HIP IPC:
+//
+//     [ flags: start[block][rank] ]  [ staging, parity 0 ]  [ staging, parity 1 ]
+//
+// One kernel per rank and call ("one shot"). Workgroup b of every rank owns slice b of the message:
+//   1. copies its slice of the input into this rank's staging buffer (parity = sequence number & 1),
+//   2. makes the copy visible (system-scope release), then one lane per peer writes the sequence
+//      number into start[b][this rank] of THAT peer's flags (a remote 4-byte store over xGMI),
+//   3. one lane per peer polls this rank's own start[b][peer] until it has reached the sequence
+//      number (bounded by a wall-clock timeout), workgroup barrier, system-scope acquire,
+//   4. reads slice b of every rank's staging buffer (remote 16-byte loads, all in flight together),
+//      adds them in fp32 in rank order and writes the bf16 sum over the input.
+// There is no second barrier: the two staging parities make it unnecessary. A rank can overwrite
+// parity p only two calls later, and it can pass the wait of the call in between only after every
+// peer has entered that call, i.e. has finished the kernel that read parity p (kernels of one rank
+// run in stream order). A peer can be at most one call ahead, hence the ">=" in the poll.
+// The sequence numbers are per workgroup and live in device memory, the kernel increments them
+// itself: a captured hipGraph replays correctly, and no workgroup ever waits for another
+// workgroup of its own rank.
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "lv_comm.h"
+#include "lv_common.h"
+
+namespace lv {
+
+constexpr int kCommMaxBlocks = 64;
+constexpr size_t kCommBlockBytes = 8192;     // message bytes per workgroup before the grid stops growing
+constexpr size_t kCommFlagBytes = 4096;      // start[64][8] words = 2 KiB, padded
+constexpr size_t kCommAllocBytes = kCommFlagBytes + 2 * static_cast<size_t>(LV_COMM_MAX_BYTES);
+
+struct CommFlags {
+  uint32_t start[kCommMaxBlocks][LV_COMM_MAX_RANKS];
+};
+static_assert(sizeof(CommFlags) <= kCommFlagBytes, "flag words must fit their region");
+
+struct CommParams {
+  uint16_t* data;
+  size_t nvec;                              // message length in 16-byte units
+  unsigned char* base[LV_COMM_MAX_RANKS];   // every rank's allocation as mapped here (own: local pointer)
+  uint32_t* epoch;                          // [kCommMaxBlocks] this rank's per-workgroup sequence numbers
+  int* dev_failed;                          // sticky: set once a wait has timed out
+  int* host_failed;                         // the same word in host-mapped memory
+  long long timeout_ticks;                  // of the 100 MHz wall clock
+  int rank, world;
+};
+
+__device__ __forceinline__ void add_bf16x8(float* acc, u32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc[2 * j] += bf16_lo(v[j]);
+    acc[2 * j + 1] += bf16_hi(v[j]);
+  }
+}
+
+// WORLD > 0: number of ranks known at compile time (loads of all ranks unrolled); 0: p.world.
+template <int WORLD>
+__global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const CommParams p) {
+  const int world = WORLD > 0 ? WORLD : p.world;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t s_epoch;
+  __shared__ int s_failed;
+  if (tid == 0) {
+    const uint32_t e = p.epoch[b] + 1;
+    p.epoch[b] = e;
+    s_epoch = e;
+    s_failed = *p.dev_failed;
+  }
+  __syncthreads();
+  const uint32_t epoch = s_epoch;
+  const size_t parity_off = kCommFlagBytes + static_cast<size_t>(epoch & 1u) * LV_COMM_MAX_BYTES;
+
+  const size_t per = (p.nvec + gridDim.x - 1) / gridDim.x;
+  const size_t lo = static_cast<size_t>(b) * per;
+  const size_t hi = lo + per < p.nvec ? lo + per : p.nvec;
+
+  // 1. publish this rank's slice
+  {
+    u32x4* mine = reinterpret_cast<u32x4*>(p.base[p.rank] + parity_off);
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.data);
+    for (size_t i = lo + tid; i < hi; i += 256) mine[i] = src[i];
+  }
+  __threadfence_system();   // every lane: its staging stores are visible to the node before the flag
+  __syncthreads();
+
+  // 2. + 3. tell every rank, then wait for every rank (one lane each)
+  if (tid < world) {
+    CommFlags* theirs = reinterpret_cast<CommFlags*>(p.base[tid]);
+    __hip_atomic_store(&theirs->start[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!s_failed) {
+      const CommFlags* mine = reinterpret_cast<const CommFlags*>(p.base[p.rank]);
+      const long long t0 = wall_clock64();
+      // relaxed system-scope loads (they bypass the caches); the acquire is the fence below
+      while (static_cast<int32_t>(__hip_atomic_load(&mine->start[b][tid], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        if (wall_clock64() - t0 > p.timeout_ticks) {   // the exit every waiting lane reaches
+          __hip_atomic_store(p.dev_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.host_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: nothing stale of the peers' slices
+
+  // 4. sum the slice over all ranks, rank order, fp32
+  u32x4* dst = reinterpret_cast<u32x4*>(p.data);
+  for (size_t i = lo + tid; i < hi; i += 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (WORLD > 0) {
+      u32x4 v[WORLD];
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) v[r] = reinterpret_cast<const u32x4*>(p.base[r] + parity_off)[i];
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) add_bf16x8(acc, v[r]);
+    } else {
+      for (int r = 0; r < world; ++r) add_bf16x8(acc, reinterpret_cast<const u32x4*>(p.base[r] + parity_off)[i]);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
+    dst[i] = o;
+  }
+}
+
+}  // namespace lv
+
+using namespace lv;
+
+struct lv_comm {
+  int rank = 0, world = 0, device = -1;
+  bool connected = false;
+  long long timeout_ticks = 0;
+  unsigned char* mine = nullptr;                       // this rank's shared allocation
+  unsigned char* base[LV_COMM_MAX_RANKS] = {};         // every rank's allocation as mapped here
+  uint32_t* epoch = nullptr;
+  int* dev_failed = nullptr;
+  int* host_failed = nullptr;                          // host pointer of the mapped word
+  int* host_failed_dev = nullptr;                      // its device pointer
+};
+
+#define LV_HIP_OK(call, what)                                                                   \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return fail(LV_ERR_COMM, "%s: %s", what, hipGetErrorString(e_));      \
+  } while (0)
+
+extern "C" {
+
+int lv_comm_create(int rank, int world_size, int timeout_ms, lv_comm_t** comm) {
+  if (!comm) return fail(LV_ERR_INVALID_ARGUMENT, "comm_create: null output pointer");
+  *comm = nullptr;
+  if (world_size < 2 || world_size > LV_COMM_MAX_RANKS || rank < 0 || rank >= world_size)
+    return fail(LV_ERR_INVALID_ARGUMENT, "comm_create: rank %d of %d (2..%d ranks)", rank, world_size,
+                LV_COMM_MAX_RANKS);
+  if (timeout_ms < 0) return fail(LV_ERR_INVALID_ARGUMENT, "comm_create: negative timeout");
+  lv_comm* c = new (std::nothrow) lv_comm();
+  if (!c) return fail(LV_ERR_COMM, "comm_create: out of host memory");
+  c->rank = rank;
+  c->world = world_size;
+  c->timeout_ticks = static_cast<long long>(timeout_ms > 0 ? timeout_ms : 10000) * 100000;   // 100 MHz
+  int rc = LV_OK;
+  do {
+    hipError_t e = hipGetDevice(&c->device);
+    if (e == hipSuccess)
+      e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->mine), kCommAllocBytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(c->mine, 0, kCommAllocBytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->epoch), kCommMaxBlocks * sizeof(uint32_t) + 256);
+    if (e == hipSuccess) e = hipMemset(c->epoch, 0, kCommMaxBlocks * sizeof(uint32_t) + 256);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->host_failed), 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+      *c->host_failed = 0;
+      e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->host_failed_dev), c->host_failed, 0);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      rc = fail(LV_ERR_COMM, "comm_create: %s", hipGetErrorString(e));
+      break;
+    }
+    c->dev_failed = reinterpret_cast<int*>(c->epoch + kCommMaxBlocks);   // behind the sequence numbers
+    c->base[rank] = c->mine;
+  } while (0);
+  if (rc != LV_OK) {
+    if (c->mine) (void)hipFree(c->mine);
+    if (c->epoch) (void)hipFree(c->epoch);
+    if (c->host_failed) (void)hipHostFree(c->host_failed);
+    delete c;
+    return rc;
+  }
+  *comm = c;
+  return LV_OK;
+}
+
+int lv_comm_get_handle(lv_comm_t* c, void* handle_out) {
+  if (!c || !handle_out) return fail(LV_ERR_INVALID_ARGUMENT, "comm_get_handle: null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == LV_COMM_HANDLE_BYTES, "IPC handle size");
+  hipIpcMemHandle_t h;
+  LV_HIP_OK(hipIpcGetMemHandle(&h, c->mine), "comm_get_handle: hipIpcGetMemHandle");
+  memcpy(handle_out, &h, sizeof(h));
+  return LV_OK;
+}
+
+int lv_comm_connect(lv_comm_t* c, const void* all_handles) {
+  if (!c || !all_handles) return fail(LV_ERR_INVALID_ARGUMENT, "comm_connect: null pointer");
+  if (c->connected) return fail(LV_ERR_INVALID_ARGUMENT, "comm_connect: already connected");
+  int dev = -1;
+  LV_HIP_OK(hipGetDevice(&dev), "comm_connect: hipGetDevice");
+  if (dev != c->device) return fail(LV_ERR_INVALID_ARGUMENT, "comm_connect: created on device %d, current is %d", c->device, dev);
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const unsigned char*>(all_handles) + static_cast<size_t>(r) * LV_COMM_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess || !ptr) {
+      for (int q = 0; q < r; ++q)
+        if (q != c->rank && c->base[q]) {
+          (void)hipIpcCloseMemHandle(c->base[q]);
+          c->base[q] = nullptr;
+        }
+      return fail(LV_ERR_COMM, "comm_connect: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+    }
+    c->base[r] = static_cast<unsigned char*>(ptr);
+  }
+  c->connected = true;
+  return LV_OK;
+}
+
+int lv_comm_failed(lv_comm_t* c) {
+  if (!c) return 1;
+  return *reinterpret_cast<volatile int*>(c->host_failed) != 0;
+}
+
+int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, lv_stream_t stream) {
+  if (!c) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: null communicator");
+  if (!c->connected) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: communicator not connected");
+  if (lv_comm_failed(c))
+    return fail(LV_ERR_COMM, "all_reduce: rank %d gave up waiting for a peer in an earlier call; the communicator is dead", c->rank);
+  if (count == 0) return LV_OK;
+  if (!data) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: null data");
+  const size_t bytes = count * 2;
+  if (bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(data) & 15u) != 0)
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce: %zu bytes at %p: 16-byte multiples and alignment required", bytes, data);
+  if (bytes > LV_COMM_MAX_BYTES)
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce: %zu bytes exceed the %u-byte limit of the direct path", bytes,
+                static_cast<unsigned>(LV_COMM_MAX_BYTES));
+  CommParams p;
+  p.data = static_cast<uint16_t*>(data);
+  p.nvec = bytes / 16;
+  for (int r = 0; r < LV_COMM_MAX_RANKS; ++r) p.base[r] = r < c->world ? c->base[r] : nullptr;
+  p.epoch = c->epoch;
+  p.dev_failed = c->dev_failed;
+  p.host_failed = c->host_failed_dev;
+  p.timeout_ticks = c->timeout_ticks;
+  p.rank = c->rank;
+  p.world = c->world;
+  size_t blocks = (bytes + kCommBlockBytes - 1) / kCommBlockBytes;
+  if (blocks > static_cast<size_t>(kCommMaxBlocks)) blocks = kCommMaxBlocks;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (c->world) {
+    case 2: hipLaunchKernelGGL((allreduce_oneshot_kernel<2>), grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((allreduce_oneshot_kernel<4>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((allreduce_oneshot_kernel<8>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((allreduce_oneshot_kernel<0>), grid, block, 0, s, p); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "all_reduce launch: %s", hipGetErrorString(e));
+  return LV_OK;
+}
+
+int lv_comm_destroy(lv_comm_t* c) {
+  if (!c) return LV_OK;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < c->world; ++r)
+    if (r != c->rank && c->base[r]) (void)hipIpcCloseMemHandle(c->base[r]);
+  if (c->mine) (void)hipFree(c->mine);
+  if (c->epoch) (void)hipFree(c->epoch);
+  if (c->host_failed) (void)hipHostFree(c->host_failed);
+  delete c;
+  return LV_OK;
+}
+
+}  // extern "C"

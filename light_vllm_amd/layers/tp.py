@@ -6,6 +6,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .. import comm as _comm
+
 
 def tp_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
@@ -23,7 +25,12 @@ def _staged(t) -> bool:
 
 
 def all_reduce(t):
-    """In-place sum over the TP group (reference: layers/linear.py:388-389)."""
+    """In-place sum over the TP group (reference: layers/linear.py:388-389). Decode-sized bf16
+    messages (up to 4 MiB) take the direct path over the peers' IPC-mapped buffers when a
+    communicator is installed (one kernel, hipGraph-capturable); everything else is RCCL."""
+    direct = _comm.active()
+    if direct is not None and direct.usable(t):
+        return direct.all_reduce(t)
     if _staged(t):
         h = t.cpu()
         dist.all_reduce(h)

@@ -4,7 +4,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("lv_attention.h",)]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("lv_attention.h", "lv_comm.h")]
 
 
 def declared_functions():
@@ -19,7 +19,9 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
-        "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static"])
+        "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
+        "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
+        "lv_comm_destroy"])
 
 
 def test_library_exports_every_declared_symbol():

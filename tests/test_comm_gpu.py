@@ -1,0 +1,135 @@
+"""Direct all-reduce (include/lv_comm.h) between processes that share cuda:0: every rank maps the
+others' buffers through HIP IPC handles exchanged over a gloo group, exactly as ranks on different
+GPUs of a node do. Results must equal the fp32 sum in rank order rounded once to bf16, bit for
+bit and identically on every rank; back-to-back calls of changing sizes exercise the two staging
+parities; a captured hipGraph must replay; a rank whose peers never arrive must give up within its
+timeout and report the communicator dead instead of spinning."""
+import json
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# elements: one 16-byte vector, a ragged count, [1, 4096] .. [256, 4096] activations, [256, 5120], the 4 MiB limit
+SIZES = [8, 8 * 37, 4096, 32 * 4096, 64 * 4096, 256 * 4096, 256 * 5120, 2 * 1024 * 1024]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(world, n, salt):
+    """Every rank's input for one call, reproducible on every rank (CPU generator)."""
+    g = torch.Generator().manual_seed(1000 * salt + n % 997)
+    return [(torch.randn(n, generator=g) * (1 + r)).to(torch.bfloat16) for r in range(world)]
+
+
+def _expected(parts):
+    acc = torch.zeros(parts[0].numel(), dtype=torch.float32)
+    for p in parts:                      # rank order, fp32, one rounding
+        acc += p.float()
+    return acc.to(torch.bfloat16)
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from light_vllm_amd import comm as lvcomm
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    res = {"rank": rank, "bad": [], "calls": 0}
+    c = lvcomm.create_for_group(dev, timeout_ms=20000)
+    assert c is not None, "IPC communicator could not be built"
+    # eager, sizes up and down, three rounds: consecutive calls alternate the staging parity
+    salt = 0
+    for rnd in range(3):
+        for n in SIZES + SIZES[::-1]:
+            salt += 1
+            parts = _inputs(world, n, salt)
+            x = parts[rank].to(dev)
+            c.all_reduce(x)
+            res["calls"] += 1
+            if not torch.equal(x.cpu().view(torch.int16), _expected(parts).view(torch.int16)):
+                res["bad"].append(("eager", rnd, n))
+    # through the layer helper the model uses
+    from light_vllm_amd.layers import tp
+    lvcomm.install(c)
+    parts = _inputs(world, 64 * 4096, 7777)
+    y = parts[rank].to(dev).view(64, 4096)
+    tp.all_reduce(y)
+    if not torch.equal(y.cpu().view(-1).view(torch.int16), _expected(parts).view(torch.int16)):
+        res["bad"].append(("tp.all_reduce",))
+    lvcomm.install(None)
+    # hipGraph: three all-reduces on static buffers, replayed on new contents
+    bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for n in (4096, 64 * 4096, 8 * 37)]
+    for b in bufs:
+        c.all_reduce(b)                  # warm run, same on every rank
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for b in bufs:
+            c.all_reduce(b)
+    for rep in range(3):
+        all_parts = [_inputs(world, b.numel(), 9000 + 10 * rep + i) for i, b in enumerate(bufs)]
+        for b, parts in zip(bufs, all_parts):
+            b.copy_(parts[rank])
+        graph.replay()
+        torch.cuda.synchronize()
+        for b, parts in zip(bufs, all_parts):
+            if not torch.equal(b.cpu().view(torch.int16), _expected(parts).view(torch.int16)):
+                res["bad"].append(("graph", rep, b.numel()))
+    res["failed_after_use"] = c.failed()
+    dist.barrier()
+    # a second communicator with a 300 ms timeout: only rank 0 calls, nobody answers
+    c2 = lvcomm.create_for_group(dev, timeout_ms=300)
+    if rank == 0:
+        z = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        c2.all_reduce(z)
+        t1.record()
+        torch.cuda.synchronize()
+        res["timeout_ms"] = t0.elapsed_time(t1)
+        res["dead"] = c2.failed()
+        try:
+            c2.all_reduce(z)
+            res["second_call"] = "accepted"
+        except RuntimeError as exc:
+            res["second_call"] = str(exc)
+    dist.barrier()                       # peers keep their buffers mapped until rank 0 is done
+    c2.close()
+    c.close()
+    with open(os.path.join(out_dir, f"comm_{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_all_reduce_shared_gpu(gpu, tmp_path, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    for r in range(world):
+        res = json.load(open(os.path.join(str(tmp_path), f"comm_{r}.json")))
+        assert not res["bad"], f"rank {r}: {res['bad'][:5]}"
+        assert res["calls"] == 3 * 2 * len(SIZES)
+        assert res["failed_after_use"] is False
+        if r == 0:
+            print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms")
+            assert res["dead"] is True
+            assert 250 <= res["timeout_ms"] <= 5000
+            assert "communicator" in res["second_call"]
