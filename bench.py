@@ -4,27 +4,35 @@ Metric (BASELINE.json): paged-decode attention HBM GB/s. One "step" is one decod
 path over every layer of the model: per layer, lv_store_kvcache of the step's new token rows, then
 lv_decode_attn over the paged cache (what Attention.forward does once per layer per decode step).
 
-Workload at N=1: BASELINE.json configs[1] — Qwen3-0.6B shapes (28 layers, 16 q / 8 kv heads, D=128),
-bf16, batch 256, every sequence at 1024 tokens of context, block size 256, a seeded random physical
-block permutation. At N>1 the path shards by KV head (tensor parallel rank r owns 8/N kv heads and
-16/N q heads, no data-path collective inside attention); the batch grows to 256*N so per-GPU bytes
-stay fixed ("weak" scaling: TP used to serve a proportionally larger batch).
+N = 1   BASELINE.json configs[1]: Qwen3-0.6B shapes (28 layers, 16 q / 8 kv heads, D=128), bf16,
+        batch 256, every sequence at 1024 tokens of context, block size 256, a seeded random physical
+        block permutation. `roofline` is its decode kernel (decode_attn_kernel<2,8>); `roofline_8b`
+        is the same launch on Qwen3-8B TP=1 shapes (36 layers, 32 q / 8 kv heads: decode_mfma_kernel<4>),
+        the configuration the 70 %-of-HBM-peak target is stated on.
+N > 1   BASELINE.json configs[3]: Qwen3-8B under tensor parallelism TP = N. The path shards by KV
+        head: rank r owns 8/N kv heads and 32/N q heads of every layer, a fixed GLOBAL batch of 32
+        sequences at 32k tokens of context ([32, 128] block table), so the work per step is fixed
+        and N divides it ("strong" scaling). What TP costs sits inside the timed step: per layer,
+        after store + decode, one sum all-reduce of the [batch, 4096] bf16 activation (the o_proj
+        all-reduce of RowParallelLinear, lightvllm/layers/linear.py:388-389) through the same
+        layers.tp.all_reduce the model calls (direct IPC path when available, else RCCL). The 36
+        layers of a step are captured in one hipGraph and the timed steps are replays.
 
-`value` = algorithmic bytes of all launches of a step, summed over ranks, / max-over-ranks step time.
-Inputs are resident in HBM before the timed region.
+`value` = algorithmic bytes of all attention launches of a step, summed over ranks, / max-over-ranks
+step time. Inputs are resident in HBM before the timed region.
 
-After the timed region two auxiliary measurements are attached to the same JSON line (they never
-touch `value`): `collectives` times the RCCL sum all-reduce at the two message sizes the tensor-parallel
-model issues (decode: [256, 4096] bf16 = 2 MiB, prefill: [16384, 4096] bf16 = 128 MiB), and `e2e`
-is the engine's own decode / prefill tok/s (tools/e2e_bench.py: Qwen3-8B shapes, random weights,
-TP = N, one process per GPU) run in a child process with its own time limit, so a failure there
-is reported as text and cannot take the headline number with it. `--no-aux` skips both.
+Auxiliary records on the same JSON line (never part of `value`): `cpu_baseline` (N=1: the CPU oracle
+on the host cores), `prefill` (the prefill kernel on the 4 x 4096 configuration), `config4_tp1`
+(N=1: the N>1 step at TP=1, the base of the strong-scaling curve), `collectives` (N>1: all-reduce
+latencies, direct path and RCCL) and `e2e` (the engine's tok/s at TP = N in child processes; a
+failure there sets `e2e_failed`). `--no-aux` skips them.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import signal
@@ -38,9 +46,13 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-LAYERS, HQ_TOTAL, HKV_TOTAL, D, BLOCK = 28, 16, 8, 128, 256
-BATCH_PER_GPU, CTX = 256, 1024
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X
+D, BLOCK = 128, 256
+C2 = dict(name="Qwen3-0.6B", layers=28, hq=16, hkv=8, batch=256, ctx=1024)          # configs[1]
+C2_8B = dict(name="Qwen3-8B", layers=36, hq=32, hkv=8, batch=256, ctx=1024)         # north-star shapes
+C4 = dict(name="Qwen3-8B", layers=36, hq=32, hkv=8, batch=32, ctx=32768, hidden=4096)  # configs[3]
+TUNED_GEMMS = os.path.join(ROOT, "tools", "tunable", "tunableop.csv")   # PyTorch appends the device ordinal
 
 
 def decode_bytes(B, ctx, Hq, Hkv):
@@ -54,59 +66,148 @@ def store_bytes(N, Hkv):
     return 2 * (N * Hkv * D * 2 * 2) + 4 * N
 
 
-def cpu_baseline(case_cpu, Hq, Hkv, budget_s=12.0):
-    """Times the CPU oracle (torch fp32 attention over block_table-gathered K/V) on one layer of
-    the same workload, repeated until ~budget_s of CPU work is done."""
-    from oracle.attention_oracle import decode_ref
-    q, kc, vc, ctx, bt, scale = case_cpu
-    B = q.size(0)
-    t0 = time.perf_counter()
-    decode_ref(q[:4], kc, vc, ctx[:4], bt[:4], scale)  # touch pages / warm threads
-    reps, t_used = 0, 0.0
-    t0 = time.perf_counter()
-    while True:
-        decode_ref(q, kc, vc, ctx, bt, scale)
-        reps += 1
-        t_used = time.perf_counter() - t0
-        if t_used >= budget_s or reps >= 50:
-            break
-    per_call = t_used / reps
-    gbs = decode_bytes(B, int(ctx[0]), Hq, Hkv) / per_call / 1e9
-    return {"value": round(gbs, 3), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle decode_ref, 1 layer of the workload (B={B}, ctx={int(ctx[0])}, Hq={Hq}, Hkv={Hkv}), "
-                      f"{reps} calls, {per_call * 1e3:.1f} ms/call"}
+class DecodeWorkload:
+    """The per-layer tensors of one decode step on this rank: one KV tensor for all layers, as
+    ModelRunner.allocate_kv_cache lays it out, so no layer's cache is served from the Infinity Cache
+    of the layer before."""
 
+    def __init__(self, ops, dev, layers, Hq, Hkv, B, ctx, seed):
+        self.ops, self.dev, self.layers, self.Hq, self.Hkv, self.B, self.ctx = ops, dev, layers, Hq, Hkv, B, ctx
+        bps = ctx // BLOCK
+        nblk = B * bps
+        gen = torch.Generator().manual_seed(seed)
+        self.kv = torch.empty(2, layers, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev)
+        for l in range(layers):
+            self.kv[0, l].normal_()
+            self.kv[1, l].normal_()
+        self.q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
+        self.k_new = torch.randn(B, Hkv, D, device=dev).to(torch.bfloat16)
+        qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device=dev).to(torch.bfloat16)
+        self.v_new = qkv[:, (Hq + Hkv) * D:].view(B, Hkv, D)   # V is a view into the fused activation
+        self.bt_cpu = torch.randperm(nblk, generator=gen).to(torch.int32).view(B, bps).contiguous()
+        self.ctx_cpu = torch.full((B,), ctx, dtype=torch.int32)
+        slots = (self.bt_cpu[:, -1].long() * BLOCK + (ctx - 1) % BLOCK).to(torch.int32)
+        self.bt, self.ctx_t, self.slots = self.bt_cpu.to(dev), self.ctx_cpu.to(dev), slots.to(dev)
+        self.scale = D ** -0.5
+        self.out = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
+        self.nsplit = ops.decode_num_splits(B, Hkv, bps, BLOCK)
+        ops.reserve_decode_workspace(dev, ops.decode_workspace_bytes(B, Hq, D, self.nsplit))
+        self.decode_bytes = decode_bytes(B, ctx, Hq, Hkv)
+        self.step_bytes = layers * (self.decode_bytes + store_bytes(B, Hkv))
 
-def allreduce_bench(dist, dev, n, iters=20):
-    """Average time of an in-place bf16 sum all-reduce (the collective RowParallelLinear and the
-    vocab-parallel embedding issue) at decode- and prefill-sized messages; busbw = 2(n-1)/n * S / t."""
-    out = {}
-    for name, rows in (("decode_2MiB", 256), ("prefill_128MiB", 16384)):
-        x = torch.ones(rows, 4096, dtype=torch.bfloat16, device=dev)
-        for _ in range(3):
-            dist.all_reduce(x)
-            x.fill_(1.0)
+    def step(self, events=None, after_layer=None):
+        ops, kv = self.ops, self.kv
+        for l in range(self.layers):
+            ops.store_kvcache(self.k_new, self.v_new, kv[0, l], kv[1, l], self.slots)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.decode_attention(self.q, kv[0, l], kv[1, l], self.ctx_t, self.bt, self.scale, out=self.out)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
+            if after_layer is not None:
+                after_layer()
+
+    def roofline(self, steps, kernel):
+        """Events around every decode launch of `steps` eager passes, on the launch stream."""
+        events = []
+        self.step()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            dist.all_reduce(x)
-        e1.record()
+        for _ in range(steps):
+            self.step(events)
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        out[name] = {"avg_us": round(us, 1),
-                     "busbw_GBs": round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)}
-        del x
-    return out
+        avg_s = sum(a.elapsed_time(b) for a, b in events) / len(events) / 1e3
+        achieved = self.decode_bytes / avg_s / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": self.decode_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                "launches_timed": len(events),
+                "shape": f"B={self.B} ctx={self.ctx} {self.Hq}q/{self.Hkv}kv x {self.layers} layers, splits {self.nsplit}"}
+
+    def free(self):
+        del self.kv, self.q, self.k_new, self.v_new, self.out
+        torch.cuda.empty_cache()
 
 
-TUNED_GEMMS = os.path.join(ROOT, "tools", "tunable", "tunableop.csv")   # PyTorch appends the device ordinal
+def recorded_traffic():
+    """HBM bytes per launch of the config-2 decode kernel from the PMC passes of tools/pmc_decode.sh
+    (profiles/decode_traffic.json). A recording, not a measurement of this run: returned only while
+    the kernel source it was taken on is the one in the tree."""
+    path = os.path.join(ROOT, "profiles", "decode_traffic.json")
+    src = os.path.join(ROOT, "light_vllm_amd", "csrc", "decode_attn.hip")
+    try:
+        rec = json.load(open(path))
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except (OSError, ValueError):
+        return None, {"kind": "none"}
+    source = {"kind": "recorded PMC passes (FETCH_SIZE, WRITE_SIZE), not collected in this run",
+              "file": "profiles/decode_traffic.json", "kernel": rec.get("kernel"),
+              "recorded_on_kernel_source": rec.get("kernel_source_sha16"), "current_kernel_source": sha}
+    if rec.get("kernel_source_sha16") != sha:
+        source["kind"] = "stale: recorded on another version of decode_attn.hip, dropped"
+        return None, source
+    return rec.get("hbm_bytes_per_launch"), source
 
 
-MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def prefill_leg(torch, ops, dev, n, iters=50, warmup=20):
+def cpu_baseline(w, budget_s=10.0):
+    """The CPU oracle (torch fp32 attention over block_table-gathered K/V, the reference's CPU
+    plumbing path of BASELINE config 1) on one layer of the config-2 workload, on the threads this
+    job owns; then a single-thread leg on 32 of the 256 sequences, and the config-3 prefill on
+    1 x 4096 tokens (a quarter of its batch), each bounded in time."""
+    from oracle.attention_oracle import decode_ref, prefill_ref
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    q, kc, vc = w.q.cpu(), w.kv[0, 0].cpu(), w.kv[1, 0].cpu()
+    ctx, bt, scale = w.ctx_cpu, w.bt_cpu, w.scale
+
+    def timed(fn, budget, max_reps):
+        fn()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            reps += 1
+            used = time.perf_counter() - t0
+            if used >= budget or reps >= max_reps:
+                return used / reps, reps
+
+    per_call, reps = timed(lambda: decode_ref(q, kc, vc, ctx, bt, scale), budget_s, 50)
+    rec = {"value": round(w.decode_bytes / per_call / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+           "sample": f"oracle decode_ref, 1 layer of the workload (B={w.B}, ctx={w.ctx}, Hq={w.Hq}, Hkv={w.Hkv}), "
+                     f"{reps} calls, {per_call * 1e3:.1f} ms/call",
+           "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+           "threads_note": "threads = this job's CPU share (OMP_NUM_THREADS), not the host's core count"}
+    torch.set_num_threads(1)
+    nb = 32
+    per1, reps1 = timed(lambda: decode_ref(q[:nb], kc, vc, ctx[:nb], bt[:nb], scale), 4.0, 10)
+    rec["single_thread"] = {"value": round(decode_bytes(nb, w.ctx, w.Hq, w.Hkv) / per1 / 1e9, 3), "unit": "GB/s",
+                            "cores": 1, "sample": f"first {nb} sequences of the same layer, {reps1} calls, {per1 * 1e3:.1f} ms/call"}
+    torch.set_num_threads(threads)
+    L, Hq, Hkv = 4096, 32, 8
+    g = torch.Generator().manual_seed(3)
+    pq = torch.randn(L, Hq, D, generator=g).to(torch.bfloat16)
+    pk = torch.randn(L, Hkv, D, generator=g).to(torch.bfloat16)
+    pv = torch.randn(L, Hkv, D, generator=g).to(torch.bfloat16)
+    cu = torch.tensor([0, L], dtype=torch.int32)
+    perp, repsp = timed(lambda: prefill_ref(pq, pk, pv, cu, cu, scale), 4.0, 10)
+    flops = 4 * Hq * D * (L * L - L * (L - 1) // 2)
+    rec["prefill"] = {"value": round(flops / perp / 1e12, 4), "unit": "TFLOP/s", "cores": threads,
+                      "sample": f"oracle prefill_ref, 1 x {L} tokens of the 4 x 4096 configuration ({Hq}q/{Hkv}kv), "
+                                f"{repsp} calls, {perp * 1e3:.0f} ms/call"}
+    return rec
+
+
+def prefill_leg(ops, dev, n, iters=50, warmup=20):
     """Varlen causal prefill attention of the Qwen3-8B prefill configuration (4 x 4096-token
     prompts, packed) on this rank's TP head share: TFLOP/s of the algorithmic causal FLOP count
     and the fraction of the dense bf16 matrix peak, timed with events on the launch stream.
@@ -135,6 +236,41 @@ def prefill_leg(torch, ops, dev, n, iters=50, warmup=20):
             "launches": iters, "untimed_launches": warmup, "ms": round(ms, 4),
             "tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "bound": "mfma", "flops_per_launch": flops}
+
+
+def time_all_reduce(fn, x, iters=50):
+    for _ in range(5):
+        fn(x)
+        x.fill_(1.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def collectives_leg(dist, dev, n, direct):
+    """Average time of the in-place bf16 sum all-reduce of the TP model at its decode-sized
+    messages ([32, 4096] and [256, 4096]) on the direct IPC path and on RCCL, and at the
+    prefill-sized message ([16384, 4096], RCCL only); busbw = 2(n-1)/n * bytes / t."""
+    out = {}
+    for name, rows in (("decode_256KiB", 32), ("decode_2MiB", 256), ("prefill_128MiB", 16384)):
+        x = torch.ones(rows, 4096, dtype=torch.bfloat16, device=dev)
+        rec = {}
+        if dist.get_backend() == "nccl":
+            us = time_all_reduce(dist.all_reduce, x, iters=50 if rows <= 256 else 10)
+            rec["rccl_us"] = round(us, 1)
+            rec["rccl_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
+        if direct is not None and direct.usable(x):
+            us = time_all_reduce(direct.all_reduce, x)
+            rec["direct_us"] = round(us, 1)
+            rec["direct_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
+        out[name] = rec
+        del x
+    return out
 
 
 def e2e_leg(n, port, mode, limit_s, tuned_gemms=False):
@@ -174,13 +310,50 @@ def e2e_leg(n, port, mode, limit_s, tuned_gemms=False):
     return {"mode": mode, "error": f"exit code {proc.returncode}: {err.strip()[-300:]}"}
 
 
+def tp_step_setup(ops, dev, n, rank, cfg, layers, batch):
+    """The config-4 step on this rank: workload + the activation the per-layer all-reduce sums."""
+    w = DecodeWorkload(ops, dev, layers, cfg["hq"] // n, cfg["hkv"] // n, batch, cfg["ctx"], seed=4321 + rank)
+    hidden = torch.ones(batch, cfg["hidden"], dtype=torch.bfloat16, device=dev)
+    return w, hidden
+
+
+def run_steps(step, steps, warmup, sync_all, use_graph):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides. With use_graph the
+    step is captured once and the timed steps are replays. Returns (elapsed seconds, graph used, note)."""
+    note = None
+    graph = None
+    if use_graph:
+        try:
+            step()                                   # warm run outside capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as exc:                      # reported on the line; the eager step still measures
+            note = f"hipGraph capture failed, eager steps timed instead: {exc!r}"[:300]
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(warmup):
+        run()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync_all()
+    return time.perf_counter() - t0, graph is not None, note
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-aux", action="store_true", help="skip the collectives and e2e legs")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on ONE GPU: every rank on cuda:0, gloo group, 4 layers, batch 8 "
+                         "(proves launcher, rendezvous, graph and JSON path; not a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,53 +364,26 @@ def main():
         if world == 1 and n > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {n} but WORLD_SIZE={world}")
-    if HKV_TOTAL % n != 0:
+    if C4["hkv"] % n != 0:
         raise SystemExit("--gpus must divide the 8 KV heads (1, 2, 4 or 8)")
 
     from light_vllm_amd import ops
     import torch.distributed as dist
 
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device("cuda:0" if args.rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    direct = None
+    backend = None
     if n > 1:
+        from light_vllm_amd import comm as lvcomm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", world_size=world, rank=rank, device_id=dev)
-
-    Hq, Hkv = HQ_TOTAL // n, HKV_TOTAL // n
-    B = BATCH_PER_GPU * n
-    blocks_per_seq = CTX // BLOCK
-    nblk = B * blocks_per_seq
-    gen = torch.Generator().manual_seed(1234 + rank)
-
-    # one KV tensor for all layers, as ModelRunner.allocate_kv_cache lays it out
-    kv = torch.empty(2, LAYERS, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev)
-    for l in range(LAYERS):
-        kv[0, l].normal_()
-        kv[1, l].normal_()
-    q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
-    k_new = torch.randn(B, Hkv, D, device=dev).to(torch.bfloat16)
-    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device=dev).to(torch.bfloat16)
-    v_new = qkv[:, (Hq + Hkv) * D:].view(B, Hkv, D)   # V is a view into the fused activation
-    perm = torch.randperm(nblk, generator=gen).to(torch.int32)
-    bt_cpu = perm.view(B, blocks_per_seq).contiguous()
-    ctx_cpu = torch.full((B,), CTX, dtype=torch.int32)
-    slots_cpu = (bt_cpu[:, -1].long() * BLOCK + (CTX - 1) % BLOCK).to(torch.int32)
-    bt, ctx, slots = bt_cpu.to(dev), ctx_cpu.to(dev), slots_cpu.to(dev)
-    scale = D ** -0.5
-    out = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
-    nsplit = ops.decode_num_splits(B, Hkv, blocks_per_seq, BLOCK)
-    ops.reserve_decode_workspace(dev, ops.decode_workspace_bytes(B, Hq, D, nsplit))
-
-    def step(events=None):
-        for l in range(LAYERS):
-            ops.store_kvcache(k_new, v_new, kv[0, l], kv[1, l], slots)
-            if events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            ops.decode_attention(q, kv[0, l], kv[1, l], ctx, bt, scale, out=out)
-            if events is not None:
-                e1.record()
-                events.append((e0, e1))
+        if args.rehearse:
+            dist.init_process_group("gloo", world_size=world, rank=rank)
+        else:
+            dist.init_process_group("nccl", world_size=world, rank=rank, device_id=dev)
+        backend = dist.get_backend()
+        direct = lvcomm.create_for_group(dev)
+        lvcomm.install(direct)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -245,89 +391,116 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    events = []
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if n > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    result = {"metric": "paged-decode attn HBM GB/s", "unit": "GB/s", "n_gpus": n, "steps": args.steps,
+              "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "bf16",
+              "data": "synthetic (seeded N(0,1) bf16 q/K/V, random physical block permutation)"}
+
+    if n == 1:
+        c = C2
+        w = DecodeWorkload(ops, dev, c["layers"], c["hq"], c["hkv"], c["batch"], c["ctx"], seed=1234)
+        elapsed, _, _ = run_steps(w.step, args.steps, args.warmup, sync_all, use_graph=False)
+        value = w.step_bytes * args.steps / elapsed / 1e9
+        roof = w.roofline(args.steps, "decode_attn_kernel<2,8>")
+        roof["traffic"], roof["traffic_source"] = recorded_traffic()
+        result.update({
+            "value": round(value, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak",
+            "config": {"workload": f"BASELINE config 2: {c['name']} shapes TP=1: {c['layers']} layers x (store_kvcache + "
+                                   f"paged decode), global batch {c['batch']}, ctx {c['ctx']}, block {BLOCK}, "
+                                   f"heads {c['hq']}q/{c['hkv']}kv, D={D}, eager launches",
+                       "global_batch": c["batch"], "context_len": c["ctx"], "parallelism": "tp1",
+                       "decode_splits": w.nsplit},
+            "pct_hbm_peak": round(100.0 * roof["frac"], 2), "roofline": roof})
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(w)
+        w.free()
+        # the same launch on Qwen3-8B TP=1 shapes: the matrix-core decode kernel
+        c8 = C2_8B
+        w8 = DecodeWorkload(ops, dev, c8["layers"], c8["hq"], c8["hkv"], c8["batch"], c8["ctx"], seed=1235)
+        el8, _, _ = run_steps(w8.step, max(args.steps // 2, 2), 2, sync_all, use_graph=False)
+        r8 = w8.roofline(max(args.steps // 2, 2), "decode_mfma_kernel<4>")
+        r8["step_GBs"] = round(w8.step_bytes * max(args.steps // 2, 2) / el8 / 1e9, 2)
+        r8["workload"] = (f"{c8['name']} shapes TP=1: {c8['layers']} layers x (store_kvcache + paged decode), batch "
+                          f"{c8['batch']}, ctx {c8['ctx']}, heads {c8['hq']}q/{c8['hkv']}kv")
+        result["roofline_8b"] = r8
+        w8.free()
+    else:
+        c = C4
+        layers, batch = (4, 8) if args.rehearse else (c["layers"], c["batch"])
+        from light_vllm_amd.layers import tp
+        w, hidden = tp_step_setup(ops, dev, n, rank, c, layers, batch)
+        use_graph = direct is not None or backend == "nccl"
+        elapsed, graphed, note = run_steps(lambda: w.step(after_layer=lambda: tp.all_reduce(hidden)),
+                                           args.steps, args.warmup, sync_all, use_graph)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        value = n * w.step_bytes * args.steps / elapsed / 1e9
+        kern = "decode_mfma_kernel<4>"
+        roof = w.roofline(2, kern)
+        msg = batch * c["hidden"] * 2
+        result.update({
+            "value": round(value, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "strong",
+            "config": {"workload": f"BASELINE config 4: {c['name']} shapes TP={n}: {layers} layers x (store_kvcache + "
+                                   f"paged decode + all-reduce of [{batch}, {c['hidden']}] bf16), global batch {batch}, "
+                                   f"ctx {c['ctx']}, block table [{batch}, {c['ctx'] // BLOCK}], per-rank heads "
+                                   f"{w.Hq}q/{w.Hkv}kv, D={D}, " + ("hipGraph replay" if graphed else "eager launches"),
+                       "global_batch": batch, "context_len": c["ctx"], "parallelism": f"tp{n}",
+                       "decode_splits": w.nsplit, "hipgraph": graphed, "rehearsal": bool(args.rehearse),
+                       "all_reduce": "direct (lv_comm over IPC-mapped peer buffers)" if direct is not None else backend,
+                       "all_reduce_bytes": msg},
+            "rccl_ranks": dist.get_world_size(), "dist_backend": backend,
+            "pct_hbm_peak": round(100.0 * roof["frac"], 2), "roofline": roof})
+        if note:
+            result["config"]["graph_note"] = note
+        if direct is not None and direct.failed():
+            result["comm_failed"] = True
+        del hidden
+        w.free()
 
-    dec_ms = [a.elapsed_time(b) for a, b in events]
-    dec_avg_s = sum(dec_ms) / len(dec_ms) / 1e3
-    dbytes = decode_bytes(B, CTX, Hq, Hkv)
-    step_bytes = LAYERS * (dbytes + store_bytes(B, Hkv))
-    value = n * step_bytes * args.steps / elapsed / 1e9
-    achieved = dbytes / dec_avg_s / 1e9
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "decode_traffic.json")
-    if n == 1 and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    result = {
-        "metric": "paged-decode attn HBM GB/s",
-        "value": round(value, 2),
-        "unit": "GB/s",
-        "n_gpus": n,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "bf16",
-        "data": "synthetic (seeded N(0,1) bf16 q/K/V, random physical block permutation)",
-        "config": {"workload": f"Qwen3-0.6B shapes TP={n}: {LAYERS} layers x (store_kvcache + paged decode), "
-                               f"global batch {B}, ctx {CTX}, block {BLOCK}, per-GPU heads {Hq}q/{Hkv}kv, D={D}",
-                   "global_batch": B, "context_len": CTX, "parallelism": f"tp{n}",
-                   "decode_splits": nsplit},
-        "pct_hbm_peak": round(100.0 * achieved / HBM_PEAK_GBS, 2),
-        "roofline": {"bound": "hbm", "kernel": "decode_attn_kernel", "achieved": round(achieved, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "bytes_per_launch": dbytes,
-                     "avg_launch_us": round(dec_avg_s * 1e6, 2)},
-    }
-    if rank == 0 and n == 1 and not args.no_cpu_baseline:
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
-        case_cpu = (q.cpu(), kv[0, 0].cpu(), kv[1, 0].cpu(), ctx_cpu, bt_cpu, scale)
-        result["cpu_baseline"] = cpu_baseline(case_cpu, Hq, Hkv)
     t_aux = time.perf_counter()
     if rank == 0 and not args.no_aux:
         try:
-            result["prefill"] = prefill_leg(torch, ops, dev, n)
+            result["prefill"] = prefill_leg(ops, dev, n)
         except Exception as exc:   # reported, never fatal for the headline number
             result["prefill"] = {"error": repr(exc)[:300]}
+    if n == 1 and not args.no_aux:
+        # the multi-GPU step at TP=1 (no all-reduce): the base of the strong-scaling curve
+        try:
+            w4, _ = tp_step_setup(ops, dev, 1, 0, C4, C4["layers"], C4["batch"])
+            el4, graphed, note = run_steps(w4.step, 5, 2, sync_all, use_graph=True)
+            r4 = w4.roofline(1, "decode_mfma_kernel<4>")
+            result["config4_tp1"] = {"workload": f"BASELINE config 4 at TP=1: {C4['layers']} layers x (store_kvcache + paged "
+                                                 f"decode), batch {C4['batch']}, ctx {C4['ctx']}, heads {C4['hq']}q/{C4['hkv']}kv",
+                                     "value": round(w4.step_bytes * 5 / el4 / 1e9, 2), "unit": "GB/s",
+                                     "ms_per_step": round(el4 / 5 * 1e3, 4), "hipgraph": graphed, "roofline": r4}
+            w4.free()
+        except Exception as exc:
+            result["config4_tp1"] = {"error": repr(exc)[:300]}
     if n > 1 and not args.no_aux:
         try:
-            result["collectives"] = allreduce_bench(dist, dev, n)
-        except Exception as exc:   # reported, never fatal for the headline number
+            result["collectives"] = collectives_leg(dist, dev, n, direct)
+        except Exception as exc:
             result["collectives"] = {"error": repr(exc)[:300]}
-    del kv, q, k_new, qkv, v_new, out
     torch.cuda.empty_cache()
     if n > 1:
+        from light_vllm_amd import comm as lvcomm
         dist.barrier()
+        lvcomm.install(None)
+        if direct is not None:
+            direct.close()
         dist.destroy_process_group()
-    if rank == 0 and not args.no_aux:
+    if rank == 0 and not args.no_aux and not args.rehearse:
         # every bench rank has released its GPU memory; the engine starts its own one process per GPU
         port = int(os.environ.get("MASTER_PORT", "29500")) + 17
         legs = [e2e_leg(n, port, "eager", 150)]
         if "error" not in legs[0]:
-            legs.append(e2e_leg(n, port + 1, "graph", 120))
+            legs.append(e2e_leg(n, port + 1, "graph", 150))
             if n == 1 and "error" not in legs[-1] and os.path.exists(TUNED_GEMMS.replace(".csv", "0.csv")):
                 legs.append(e2e_leg(n, port + 2, "graph", 120, tuned_gemms=True))
         result["e2e"] = {"what": "tools/e2e_bench.py: engine generate(), Qwen3-8B shapes, random weights, "
                                  f"TP={n}, batch 256 x 1024-token prompts, 33 new tokens, greedy",
                          "runs": legs}
+        result["e2e_failed"] = any("error" in leg for leg in legs)
         result["aux_seconds"] = round(time.perf_counter() - t_aux, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -65,6 +65,13 @@ class ModelRunner:
             dist.init_process_group(backend, config.dist_init_method, world_size=self.world_size,
                                     rank=rank, **kwargs)
             self._own_group = True
+        # Decode-sized all-reduces go over the peers' IPC-mapped buffers (one kernel, capturable into
+        # the decode hipGraph); RCCL keeps the prefill-sized ones. Collective: all ranks or none.
+        self.direct_comm = None
+        if self.world_size > 1 and self.on_gpu and config.direct_all_reduce:
+            from .. import comm as lvcomm
+            self.direct_comm = lvcomm.create_for_group(self.device)
+            lvcomm.install(self.direct_comm)
 
         default_dtype = torch.get_default_dtype()
         dtype = getattr(hf_config, "torch_dtype", None) or getattr(hf_config, "dtype", None) or torch.bfloat16
@@ -118,6 +125,14 @@ class ModelRunner:
             del self.graphs, self.graph_pool
         if self.on_gpu:
             torch.cuda.synchronize()
+        if self.direct_comm is not None:
+            from .. import comm as lvcomm
+            failed = self.direct_comm.failed()
+            dist.barrier()                 # no peer is still reading this rank's buffers
+            lvcomm.install(None)
+            self.direct_comm.close()
+            self.direct_comm = None
+            assert not failed, "a direct all-reduce timed out waiting for a peer during this run"
         if self._own_group:
             dist.destroy_process_group()
 

@@ -35,3 +35,27 @@ def test_cli_rejects_inconsistent_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def test_decode_bytes_of_the_multi_gpu_workload():
+    b = _bench()
+    # config 4 at TP=2: 32 sequences x 32768 tokens, 16 q / 4 kv heads per rank, [32, 128] block table
+    assert b.decode_bytes(32, 32768, 16, 4) == 32 * 32768 * 4 * 128 * 4 + 2 * 32 * 16 * 128 * 2 + 4 * 32 + 4 * 32 * 128
+    assert b.C4["ctx"] // b.BLOCK == 128 and b.C4["hq"] == 32 and b.C4["hkv"] == 8 and b.C4["layers"] == 36
+
+
+def test_recorded_traffic_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
+    """The HBM-traffic figure on the bench line is a recording; it must disappear (with the reason
+    on the line) as soon as decode_attn.hip is no longer the file it was recorded on."""
+    import hashlib
+    import json
+    b = _bench()
+    value, source = b.recorded_traffic()
+    src = os.path.join(ROOT, "light_vllm_amd", "csrc", "decode_attn.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    rec = json.load(open(os.path.join(ROOT, "profiles", "decode_traffic.json")))
+    if rec.get("kernel_source_sha16") == sha:
+        assert value == rec["hbm_bytes_per_launch"] and "recorded" in source["kind"]
+    else:
+        assert value is None and "stale" in source["kind"]
+    assert source["current_kernel_source"] == sha

@@ -1,6 +1,8 @@
 """Tensor-parallel engine path through the HIP kernels, rehearsed on ONE GPU: two rank processes
-share cuda:0 and exchange through a "gloo" group staged over host memory (Config.shared_device).
-Everything but the collective transport is the production TP=2 path: per-rank head sharding
+share cuda:0 (Config.shared_device). The decode-sized all-reduces run on the direct IPC path
+(lv_comm), exactly as between two GPUs; the process group is "gloo" (RCCL refuses two ranks on one
+device), which carries the IPC handles, the prefill-sized all-reduces and the logits gather staged
+over host memory. Everything but that transport is the production TP=2 path: per-rank head sharding
 (32/8 -> 16/4 q/kv heads, the matrix-core decode kernel), per-rank KV caches with global block
 ids, the shared-memory step RPC, the masked embedding all-reduce and the logits gather
 (reference: engine/model_runner.py:116-180, layers/linear.py:240-395, layers/embed_head.py:18-197).
@@ -27,7 +29,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, event, out_path):
+def _worker(rank, world, port, event, out_path, enforce_eager=True):
     from light_vllm_amd.config import Config
     from light_vllm_amd.engine.model_runner import ModelRunner
     from light_vllm_amd.engine.scheduler import Scheduler
@@ -35,12 +37,13 @@ def _worker(rank, world, port, event, out_path):
     from light_vllm_amd.sampling_params import SamplingParams
     golden = load_golden("e2e_prefix_gqa4.json")
     cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=64, max_num_seqs=16,
-                 enforce_eager=True, random_seed=golden["seed"], tensor_parallel_size=world,
+                 enforce_eager=enforce_eager, random_seed=golden["seed"], tensor_parallel_size=world,
                  dist_backend="gloo", shared_device=True, dist_init_method=f"tcp://127.0.0.1:{port}")
     if rank != 0:
         ModelRunner(cfg, rank, event)          # serves the step RPC until "exit"
         return
     runner = ModelRunner(cfg, 0, [event])
+    assert runner.direct_comm is not None, "the rehearsal is meant to run on the direct all-reduce"
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=golden["max_tokens"], ignore_eos=True)
     seqs = [Sequence(p, sp) for p in golden_prompts(golden)]
@@ -62,13 +65,16 @@ def _worker(rank, world, port, event, out_path):
         json.dump({"compared": compared, "soft": soft, "hard": hard}, f)
 
 
-def test_tp2_shared_gpu_prefix_scenario(gpu, tmp_path):
+@pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
+def test_tp2_shared_gpu_prefix_scenario(gpu, tmp_path, enforce_eager):
+    """hipgraph: the decode graphs hold the model's 2 * layers + 1 all-reduces (direct path) next to
+    the attention kernels; every rank replays its own graph of the same bucket."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     event = ctx.Event()
     port = _free_port()
     out_path = os.path.join(str(tmp_path), "tp2.json")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, event, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, event, out_path, enforce_eager)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
