@@ -29,6 +29,7 @@ class Config:
     strict_reference: bool = False    # BlockManager.can_append as the reference tests it
     random_seed: Optional[int] = None  # random-init weights (seeded) instead of loading `model`
     random_on_device: bool = False    # benchmarks: draw the random weights on the GPU (fast, not portable)
+    random_kind: str = "normal"       # "lagcopy": utils.loader.lagcopy_checkpoint (greedy output decided with a margin)
     dist_init_method: str = "tcp://127.0.0.1:2333"
     dist_backend: Optional[str] = None  # None: "nccl" (RCCL) on GPUs, "gloo" on CPU
     shared_device: bool = False       # every rank on cuda:0 with a "gloo" group: rehearses the TP path on one GPU

@@ -83,7 +83,7 @@ class ModelRunner:
             if config.random_seed is not None and config.random_on_device:
                 load_random_on_device(self.model, config.random_seed)
             elif config.random_seed is not None:
-                load_random(self.model, hf_config, config.random_seed)
+                load_random(self.model, hf_config, config.random_seed, kind=config.random_kind)
             else:
                 load_model(self.model, config.model)
             self.sampler = Sampler()

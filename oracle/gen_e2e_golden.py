@@ -103,6 +103,19 @@ def long_prompts():
     return [torch.randint(0, 151936, (n,), generator=g).tolist() for n in (2100, 2500)]
 
 
+def lagcopy_prompts():
+    """Four prompts of 300 / 513 / 700 / 1024 random tokens for the lag-copy checkpoint
+    (light_vllm_amd.utils.loader.lagcopy_checkpoint): all longer than its 257-position lag, of
+    different block counts, one ending exactly on a block boundary."""
+    g = torch.Generator().manual_seed(79)
+    return [torch.randint(0, 151936, (n,), generator=g).tolist() for n in (300, 513, 700, 1024)]
+
+
+def bf16_ulp(x):
+    import math
+    return 2.0 ** (math.floor(math.log2(max(abs(x), 1e-30))) - 7)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=28)
@@ -110,7 +123,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "e2e_config1.json"))
     ap.add_argument("--shape", default="0.6b", choices=["0.6b", "gqa4"])
-    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix", "long"])
+    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix", "long", "lagcopy"])
+    ap.add_argument("--weights", default="normal", choices=["normal", "lagcopy"])
+    ap.add_argument("--min-gap-ulps", type=float, default=0.0,
+                    help="fail unless the top-2 logit gap of every recorded step is at least this many bf16 steps")
     args = ap.parse_args()
 
     install_stubs()
@@ -129,10 +145,10 @@ def main():
     torch.set_default_dtype(torch.bfloat16)
     model = Qwen3ForCausalLM(hf)
     torch.set_default_dtype(torch.float32)
-    load_random(model, hf, args.seed)
+    load_random(model, hf, args.seed, kind=args.weights)
     sampler = Sampler()
 
-    block_size, num_blocks = 256, (24 if args.scenario == "long" else 16)
+    block_size, num_blocks = 256, (24 if args.scenario in ("long", "lagcopy") else 16)
     kv = torch.zeros(2, hf.num_hidden_layers, num_blocks, block_size, hf.num_key_value_heads, hf.head_dim,
                      dtype=torch.bfloat16)
     layer_id = 0
@@ -145,7 +161,8 @@ def main():
                           num_kvcache_blocks=num_blocks, kvcache_block_size=block_size)
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=args.steps, ignore_eos=True)
-    prompts = {"config1": config1_prompts, "prefix": prefix_prompts, "long": long_prompts}[args.scenario]()
+    prompts = {"config1": config1_prompts, "prefix": prefix_prompts, "long": long_prompts,
+               "lagcopy": lagcopy_prompts}[args.scenario]()
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
     for s in seqs:
@@ -189,13 +206,21 @@ def main():
             sch.postprocess(batch, toks)
             print(f"step {len(steps)} prefill={is_prefill} tokens={toks} t={time.time() - t0:.1f}s", flush=True)
 
+    worst = min((rec["gap"][j] / bf16_ulp(rec["top5_logits"][j][0]), n, j) for n, rec in enumerate(steps)
+                for j in range(len(rec["tokens"])))
+    print(f"smallest top-2 gap: {worst[0]:.1f} bf16 steps of the top logit (step {worst[1]}, row {worst[2]})")
+    if worst[0] < args.min_gap_ulps:
+        raise SystemExit(f"gap {worst[0]:.1f} < required {args.min_gap_ulps} bf16 steps: not written")
+
     out = {"model": "Qwen3-0.6B shapes, random init" if args.shape == "0.6b" else
                     "Qwen3-8B head geometry (32q/8kv x 128) on hidden 1024, random init",
            "shape": args.shape, "scenario": args.scenario,
            "prompts": prompts if args.scenario != "config1" else None,
            "cached_tokens_at_prefill": [int(x) for x in cached_at_prefill],
            "layers": args.layers, "seed": args.seed,
-           "weights": "light_vllm_amd.utils.loader.random_checkpoint(seed, std=0.02)",
+           "weights": "light_vllm_amd.utils.loader.random_checkpoint(seed, std=0.02)" if args.weights == "normal"
+                      else "light_vllm_amd.utils.loader.lagcopy_checkpoint(seed)",
+           "weights_kind": args.weights, "min_gap_bf16_steps": round(worst[0], 2),
            "prompts_seed": 2026, "prompt_len": 256, "num_prompts": 4, "max_tokens": args.steps,
            "dtype": "bfloat16", "steps": steps,
            "completions": [list(s.completion_token_ids) for s in seqs]}

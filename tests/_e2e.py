@@ -57,7 +57,16 @@ def is_tie(rec, j, tie_ulps):
     return rec["gap"][j] <= tie_ulps * bf16_ulp(rec["top5_logits"][j][0]) + 1e-9
 
 
-def replay(golden, runner, scheduler, tie_ulps):
+def lagcopy_expected(prompt, steps, lag=257):
+    """What the lag-copy checkpoint (light_vllm_amd.utils.loader.lagcopy_checkpoint) must generate:
+    the prefill's last row sits at rotary position len - 1 and copies the token `lag` positions
+    back; decode rows sit at rotary position index + 1 (the reference feeds len(seq) as position),
+    so generated token number i >= 1 copies prompt index len - lag + i."""
+    n = len(prompt)
+    return [prompt[n - 1 - lag]] + [prompt[n - lag + i] for i in range(1, steps)]
+
+
+def replay(golden, runner, scheduler, tie_ulps, max_steps=None):
     """Returns (num_compared, tolerated, hard, max_dev): an argmax mismatch is tolerated only if
     the reference's own top-2 logits are tied (is_tie) and our token is in its top 5; max_dev is
     the largest |our logit - reference logit| over the reference's top-5 tokens of every step."""
@@ -71,7 +80,7 @@ def replay(golden, runner, scheduler, tie_ulps):
     for s in seqs:
         scheduler.add(s)
     compared, soft, hard, max_dev = 0, [], [], 0.0
-    for step_no, rec in enumerate(golden["steps"]):
+    for step_no, rec in enumerate(golden["steps"][:max_steps]):
         batch, is_prefill = scheduler.schedule()
         assert is_prefill == rec["prefill"], f"step {step_no}: phase differs"
         assert [index[id(s)] for s in batch] == rec["seqs"], f"step {step_no}: batch differs"
@@ -93,5 +102,5 @@ def replay(golden, runner, scheduler, tie_ulps):
                 else:
                     hard.append(item)
         scheduler.postprocess(batch, rec["tokens"])     # teacher forcing with the reference tokens
-    assert scheduler.is_finished()
+    assert max_steps is not None or scheduler.is_finished()
     return compared, soft, hard, max_dev

@@ -79,3 +79,26 @@ def test_long_prompt_scenario_matches_reference_stack():
     assert compared == 2 * golden["max_tokens"]
     assert not hard, f"token mismatches outside ties: {hard}"
     assert len(soft) <= 2, f"too many tie flips: {soft}"
+
+
+def test_lagcopy_golden_is_the_copy_pattern_and_first_steps_replay():
+    """The exact-identity fixture (tests/golden/e2e_lagcopy_256.json, recorded from the reference
+    stack with utils.loader.lagcopy_checkpoint weights): its completions are the lag-copy pattern
+    that the checkpoint's construction predicts, every recorded step has a top-2 gap of more than 8
+    bf16 steps, and this package's CPU plumbing reproduces its first steps with no flip at all."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from tests._e2e import bf16_ulp, golden_config, lagcopy_expected
+    golden = load_golden("e2e_lagcopy_256.json")
+    assert golden["weights_kind"] == "lagcopy" and golden["max_tokens"] == 256
+    for prompt, completion in zip(golden["prompts"], golden["completions"]):
+        assert completion == lagcopy_expected(prompt, 256)
+    worst = min(rec["gap"][j] / bf16_ulp(rec["top5_logits"][j][0]) for rec in golden["steps"] for j in range(4))
+    assert worst >= 8.0
+    with cpu_kernels():
+        cfg = Config(None, hf_config=golden_config(golden), device="cpu", num_kvcache_blocks=24, max_model_len=2048,
+                     max_num_batched_tokens=4096, random_seed=golden["seed"], random_kind="lagcopy")
+        runner = ModelRunner(cfg, 0, [])
+        compared, soft, hard, _ = replay(golden, runner, Scheduler(cfg), tie_ulps=0, max_steps=3)
+    assert compared == 12 and not soft and not hard

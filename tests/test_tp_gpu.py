@@ -88,3 +88,53 @@ def test_tp2_shared_gpu_prefix_scenario(gpu, tmp_path, enforce_eager):
     assert res["compared"] == 4 * golden["max_tokens"]
     assert not res["hard"], f"token mismatches outside ties: {res['hard']}"
     assert len(res["soft"]) <= res["compared"] // 10
+
+
+def _worker_lagcopy(rank, world, port, event, out_path):
+    """Free-running greedy generation of the lag-copy fixture at TP = world (hipGraph decode)."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from light_vllm_amd.engine.sequence import Sequence
+    from light_vllm_amd.sampling_params import SamplingParams
+    golden = load_golden("e2e_lagcopy_256.json")
+    cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=24, max_num_seqs=16, max_model_len=2048,
+                 enforce_eager=False, random_seed=golden["seed"], random_kind="lagcopy", tensor_parallel_size=world,
+                 dist_backend="gloo", shared_device=True, dist_init_method=f"tcp://127.0.0.1:{port}")
+    if rank != 0:
+        ModelRunner(cfg, rank, event)
+        return
+    runner = ModelRunner(cfg, 0, [event])
+    sch = Scheduler(cfg)
+    sp = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
+    seqs = [Sequence(p, sp) for p in golden["prompts"]]
+    for s in seqs:
+        sch.add(s)
+    while not sch.is_finished():
+        batch, is_prefill = sch.schedule()
+        sch.postprocess(batch, runner.call("run", batch, is_prefill))
+    runner.call("exit")
+    with open(out_path, "w") as f:
+        json.dump([list(s.completion_token_ids) for s in seqs], f)
+
+
+def test_tp2_free_running_tokens_identical(gpu, tmp_path):
+    """TP = 2 changes the summation order of every all-reduce, yet the lag-copy fixture's margins
+    (more than 140 bf16 steps at every step) make the greedy tokens independent of it: the first 64
+    generated tokens of each sequence must equal the reference stack's TP = 1 run exactly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    event = ctx.Event()
+    out_path = os.path.join(str(tmp_path), "tp2_lagcopy.json")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_lagcopy, args=(r, 2, port, event, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    got = json.load(open(out_path))
+    golden = load_golden("e2e_lagcopy_256.json")
+    assert got == [c[:64] for c in golden["completions"]]
