@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 5
+#define LV_ABI_VERSION 6
 
 /* kernel_hint of lv_decode_attn: which of the two decode kernels serves the call. */
 #define LV_DECODE_KERNEL_AUTO 0   /* by num_heads / num_kv_heads: vector-ALU for 1-2, matrix-core for 3-8 */

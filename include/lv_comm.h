@@ -43,6 +43,11 @@ extern "C" {
 #define LV_COMM_MAX_RANKS 8
 #define LV_COMM_MAX_BYTES (4u << 20)      /* largest message lv_comm_all_reduce takes */
 
+/* algorithm of lv_comm_all_reduce */
+#define LV_COMM_ALGO_AUTO 0               /* by message size and rank count */
+#define LV_COMM_ALGO_ONE_SHOT 1           /* every rank reads every rank's whole message: one exchange */
+#define LV_COMM_ALGO_TWO_SHOT 2           /* rank r sums 1/world of it and writes that to all: two exchanges */
+
 typedef struct lv_comm lv_comm_t;
 
 /*
@@ -64,9 +69,11 @@ int lv_comm_connect(lv_comm_t* comm, const void* all_handles);
 /*
  * data[i] = sum over ranks of data[i], i in [0, count), bf16, in place. count * 2 must be a multiple
  * of 16 bytes and at most LV_COMM_MAX_BYTES, data 16-byte aligned device memory of this rank.
+ * algorithm: LV_COMM_ALGO_*; both give the same bits (fp32 sums in rank order, one rounding).
+ * Every rank must pass the same algorithm for the same call.
  * Returns LV_ERR_COMM if an earlier call on this communicator timed out.
  */
-int lv_comm_all_reduce(lv_comm_t* comm, void* data, size_t count, lv_stream_t stream);
+int lv_comm_all_reduce(lv_comm_t* comm, void* data, size_t count, int algorithm, lv_stream_t stream);
 
 /* 0 while healthy; non-zero once a kernel of this rank has given up waiting (host-visible word,
  * no device synchronisation). */

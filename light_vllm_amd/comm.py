@@ -17,6 +17,7 @@ from . import _lib
 
 MAX_BYTES = 4 << 20          # LV_COMM_MAX_BYTES
 HANDLE_BYTES = 64            # LV_COMM_HANDLE_BYTES
+ALGORITHMS = {"auto": 0, "one_shot": 1, "two_shot": 2}
 
 
 class DirectAllReduce:
@@ -42,12 +43,13 @@ class DirectAllReduce:
         return (self._comm is not None and t.is_cuda and t.device == self.device and t.dtype == torch.bfloat16
                 and t.is_contiguous() and 0 < nbytes <= MAX_BYTES and nbytes % 16 == 0 and t.data_ptr() % 16 == 0)
 
-    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+    def all_reduce(self, t: torch.Tensor, algorithm: str = "auto") -> torch.Tensor:
         """In-place bf16 sum over the ranks (fp32 accumulation in rank order, identical bits on
-        every rank). Stream-ordered on torch's current stream; capturable into a hipGraph."""
+        every rank). Stream-ordered on torch's current stream; capturable into a hipGraph.
+        algorithm: "auto", "one_shot" or "two_shot" (same result; the same on every rank)."""
         assert self.usable(t), "direct all-reduce: contiguous bf16 GPU tensor of at most 4 MiB, 16-byte multiple"
         with torch.cuda.device(self.device):
-            rc = self._lib.lv_comm_all_reduce(self._comm, t.data_ptr(), t.numel(),
+            rc = self._lib.lv_comm_all_reduce(self._comm, t.data_ptr(), t.numel(), ALGORITHMS[algorithm],
                                               torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "lv_comm_all_reduce")
         return t

@@ -21,6 +21,14 @@
 // The sequence numbers are per workgroup and live in device memory, the kernel increments them
 // itself: a captured hipGraph replays correctly, and no workgroup ever waits for another
 // workgroup of its own rank.
+//
+// "Two shot" for larger messages on many ranks (one shot reads (n-1) x the message per rank):
+// after the same publish + wait, rank r sums only sub-slice r of slice b over all ranks and writes
+// the bf16 result into sub-slice r of EVERY rank's staging buffer - in place: rank r is the only
+// reader of that sub-slice anywhere, and it has finished reading before it writes - then a second
+// flag exchange (done[b][rank]) and every rank copies slice b out of its own staging buffer.
+// (n-1)/n of the message read and as much written remotely per rank; same sums, same bits.
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -37,7 +45,8 @@ constexpr size_t kCommFlagBytes = 4096;      // start[64][8] words = 2 KiB, padd
 constexpr size_t kCommAllocBytes = kCommFlagBytes + 2 * static_cast<size_t>(LV_COMM_MAX_BYTES);
 
 struct CommFlags {
-  uint32_t start[kCommMaxBlocks][LV_COMM_MAX_RANKS];
+  uint32_t start[kCommMaxBlocks][LV_COMM_MAX_RANKS];   // "rank r has published slice b of call e"
+  uint32_t done[kCommMaxBlocks][LV_COMM_MAX_RANKS];    // two shot: "rank r has written its sums of slice b"
 };
 static_assert(sizeof(CommFlags) <= kCommFlagBytes, "flag words must fit their region");
 
@@ -60,9 +69,32 @@ __device__ __forceinline__ void add_bf16x8(float* acc, u32x4 v) {
   }
 }
 
+// One lane per rank: store `epoch` into word [b][p.rank] of every rank's flag array at byte offset
+// `which` (start or done), then poll this rank's own word [b][lane's rank] until it has got there.
+__device__ __forceinline__ void flag_exchange(const CommParams& p, int world, int b, int tid, size_t which,
+                                              uint32_t epoch, int failed) {
+  if (tid < world) {
+    uint32_t* theirs = reinterpret_cast<uint32_t*>(p.base[tid] + which) + b * LV_COMM_MAX_RANKS + p.rank;
+    __hip_atomic_store(theirs, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!failed) {
+      const uint32_t* mine = reinterpret_cast<const uint32_t*>(p.base[p.rank] + which) + b * LV_COMM_MAX_RANKS + tid;
+      const long long t0 = wall_clock64();
+      // relaxed system-scope loads (they bypass the caches); the acquire is the caller's fence
+      while (static_cast<int32_t>(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        if (wall_clock64() - t0 > p.timeout_ticks) {   // the exit every waiting lane reaches
+          __hip_atomic_store(p.dev_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p.host_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+  }
+}
+
 // WORLD > 0: number of ranks known at compile time (loads of all ranks unrolled); 0: p.world.
-template <int WORLD>
-__global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const CommParams p) {
+template <int WORLD, bool TWO_SHOT>
+__global__ __launch_bounds__(256) void allreduce_kernel(const CommParams p) {
   const int world = WORLD > 0 ? WORLD : p.world;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -92,30 +124,20 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const CommParams
   __syncthreads();
 
   // 2. + 3. tell every rank, then wait for every rank (one lane each)
-  if (tid < world) {
-    CommFlags* theirs = reinterpret_cast<CommFlags*>(p.base[tid]);
-    __hip_atomic_store(&theirs->start[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!s_failed) {
-      const CommFlags* mine = reinterpret_cast<const CommFlags*>(p.base[p.rank]);
-      const long long t0 = wall_clock64();
-      // relaxed system-scope loads (they bypass the caches); the acquire is the fence below
-      while (static_cast<int32_t>(__hip_atomic_load(&mine->start[b][tid], __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-        if (wall_clock64() - t0 > p.timeout_ticks) {   // the exit every waiting lane reaches
-          __hip_atomic_store(p.dev_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(p.host_failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-  }
+  flag_exchange(p, world, b, tid, offsetof(CommFlags, start), epoch, s_failed);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: nothing stale of the peers' slices
 
-  // 4. sum the slice over all ranks, rank order, fp32
+  // 4. sum over all ranks, rank order, fp32. One shot: the whole slice, straight into the output.
+  //    Two shot: this rank's sub-slice only, into every rank's staging buffer.
+  size_t slo = lo, shi = hi;
+  if constexpr (TWO_SHOT) {
+    const size_t per2 = (hi - lo + world - 1) / world;
+    slo = lo + p.rank * per2 < hi ? lo + p.rank * per2 : hi;
+    shi = slo + per2 < hi ? slo + per2 : hi;
+  }
   u32x4* dst = reinterpret_cast<u32x4*>(p.data);
-  for (size_t i = lo + tid; i < hi; i += 256) {
+  for (size_t i = slo + tid; i < shi; i += 256) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (WORLD > 0) {
       u32x4 v[WORLD];
@@ -129,7 +151,21 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const CommParams
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
-    dst[i] = o;
+    if constexpr (TWO_SHOT) {
+      for (int r = 0; r < world; ++r) reinterpret_cast<u32x4*>(p.base[r] + parity_off)[i] = o;
+    } else {
+      dst[i] = o;
+    }
+  }
+  if constexpr (TWO_SHOT) {
+    // 5. every rank's sums of slice b have landed in this rank's staging buffer: copy the slice out
+    __threadfence_system();
+    __syncthreads();
+    flag_exchange(p, world, b, tid, offsetof(CommFlags, done), epoch, s_failed);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const u32x4* mine = reinterpret_cast<const u32x4*>(p.base[p.rank] + parity_off);
+    for (size_t i = lo + tid; i < hi; i += 256) dst[i] = mine[i];
   }
 }
 
@@ -241,11 +277,13 @@ int lv_comm_failed(lv_comm_t* c) {
   return *reinterpret_cast<volatile int*>(c->host_failed) != 0;
 }
 
-int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, lv_stream_t stream) {
+int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, int algorithm, lv_stream_t stream) {
   if (!c) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: null communicator");
   if (!c->connected) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: communicator not connected");
   if (lv_comm_failed(c))
     return fail(LV_ERR_COMM, "all_reduce: rank %d gave up waiting for a peer in an earlier call; the communicator is dead", c->rank);
+  if (algorithm != LV_COMM_ALGO_AUTO && algorithm != LV_COMM_ALGO_ONE_SHOT && algorithm != LV_COMM_ALGO_TWO_SHOT)
+    return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: algorithm %d", algorithm);
   if (count == 0) return LV_OK;
   if (!data) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce: null data");
   const size_t bytes = count * 2;
@@ -268,11 +306,26 @@ int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, lv_stream_t strea
   if (blocks > static_cast<size_t>(kCommMaxBlocks)) blocks = kCommMaxBlocks;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (c->world) {
-    case 2: hipLaunchKernelGGL((allreduce_oneshot_kernel<2>), grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((allreduce_oneshot_kernel<4>), grid, block, 0, s, p); break;
-    case 8: hipLaunchKernelGGL((allreduce_oneshot_kernel<8>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((allreduce_oneshot_kernel<0>), grid, block, 0, s, p); break;
+  // One shot moves (world - 1) x the message into every rank, two shot 2 (world - 1) / world of it in
+  // two exchanges: two shot once the one-shot inflow passes 2 MiB (8 ranks: messages over 292 KiB,
+  // 4 ranks: over 683 KiB, 2 ranks: never). Set from the byte counts alone; no run across two GPUs
+  // has tuned it yet.
+  const bool two = algorithm == LV_COMM_ALGO_TWO_SHOT ||
+                   (algorithm == LV_COMM_ALGO_AUTO && static_cast<size_t>(c->world - 1) * bytes > (2u << 20));
+  if (two) {
+    switch (c->world) {
+      case 2: hipLaunchKernelGGL((allreduce_kernel<2, true>), grid, block, 0, s, p); break;
+      case 4: hipLaunchKernelGGL((allreduce_kernel<4, true>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((allreduce_kernel<8, true>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((allreduce_kernel<0, true>), grid, block, 0, s, p); break;
+    }
+  } else {
+    switch (c->world) {
+      case 2: hipLaunchKernelGGL((allreduce_kernel<2, false>), grid, block, 0, s, p); break;
+      case 4: hipLaunchKernelGGL((allreduce_kernel<4, false>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((allreduce_kernel<8, false>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((allreduce_kernel<0, false>), grid, block, 0, s, p); break;
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "all_reduce launch: %s", hipGetErrorString(e));

@@ -51,11 +51,12 @@ def _worker(rank, world, port, out_dir):
         for n in SIZES + SIZES[::-1]:
             salt += 1
             parts = _inputs(world, n, salt)
+            algo = ("auto", "one_shot", "two_shot")[(salt + rnd) % 3]     # the same on every rank
             x = parts[rank].to(dev)
-            c.all_reduce(x)
+            c.all_reduce(x, algo)
             res["calls"] += 1
             if not torch.equal(x.cpu().view(torch.int16), _expected(parts).view(torch.int16)):
-                res["bad"].append(("eager", rnd, n))
+                res["bad"].append((algo, rnd, n))
     # through the layer helper the model uses
     from light_vllm_amd.layers import tp
     lvcomm.install(c)
@@ -72,8 +73,8 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        for b in bufs:
-            c.all_reduce(b)
+        for b, algo in zip(bufs, ("one_shot", "two_shot", "two_shot")):
+            c.all_reduce(b, algo)
     for rep in range(3):
         all_parts = [_inputs(world, b.numel(), 9000 + 10 * rep + i) for i, b in enumerate(bufs)]
         for b, parts in zip(bufs, all_parts):
