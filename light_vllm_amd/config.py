@@ -25,23 +25,19 @@ class Config:
     eos: int = -1
     kernel_backend: str = "native"    # accepted for signature parity; there is a single kernel path
     # --- additions
-    device: str = "cuda"              # "cpu" only for plumbing tests that substitute the kernels
+    device: str = "cuda"              # "cuda": rank r runs on cuda:r; "cuda:<i>": every rank on that device; "cpu": plumbing tests that substitute the kernels
     strict_reference: bool = False    # BlockManager.can_append as the reference tests it
     random_seed: Optional[int] = None  # random-init weights (seeded) instead of loading `model`
     random_on_device: bool = False    # benchmarks: draw the random weights on the GPU (fast, not portable)
     random_kind: str = "normal"       # "lagcopy": utils.loader.lagcopy_checkpoint (greedy output decided with a margin)
     dist_init_method: str = "tcp://127.0.0.1:2333"
     dist_backend: Optional[str] = None  # None: "nccl" (RCCL) on GPUs, "gloo" on CPU
-    shared_device: bool = False       # every rank on cuda:0 with a "gloo" group: rehearses the TP path on one GPU
     direct_all_reduce: bool = True    # TP > 1 on GPUs: decode-sized all-reduces over IPC-mapped peer buffers (lv_comm)
 
     def __post_init__(self):
         assert self.kvcache_block_size % 256 == 0, "kvcache_block_size must be a multiple of 256"
         assert 1 <= self.tensor_parallel_size <= 8
-        if self.shared_device:
-            assert self.dist_backend == "gloo", "shared_device needs dist_backend='gloo'"
-            # hipGraph decode needs every collective inside the graph to be capturable: the direct path
-            assert self.enforce_eager or self.direct_all_reduce, "shared_device with hipGraph decode needs direct_all_reduce"
+        assert self.device == "cpu" or self.device == "cuda" or self.device.startswith("cuda:")
         if self.hf_config is None:
             assert self.model is not None and os.path.isdir(self.model), f"'{self.model}' is not a model directory"
             from transformers import AutoConfig

@@ -54,7 +54,7 @@ class ModelRunner:
         self.on_gpu = config.device != "cpu"
 
         if self.on_gpu:
-            self.device = torch.device(f"cuda:{0 if config.shared_device else rank}")
+            self.device = torch.device(config.device if ":" in config.device else f"cuda:{rank}")
             torch.cuda.set_device(self.device)
         else:
             self.device = torch.device("cpu")

@@ -17,11 +17,15 @@ def tp_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def _staged(t) -> bool:
-    """True when the collective has to go through host memory: a GPU tensor on a "gloo" group,
-    the single-GPU rehearsal of the tensor-parallel path (Config.shared_device). Never taken
-    with the "nccl" backend."""
-    return t.is_cuda and dist.get_backend() == "gloo"
+# Callers whose process group cannot carry the tensors as they are (a harness that rehearses the
+# GPU path over a host-only group) install their own carrier for what the direct path does not
+# take: an object with all_reduce(t) and gather_to_rank0(t). None: torch.distributed as is.
+_CARRIER = None
+
+
+def set_carrier(carrier) -> None:
+    global _CARRIER
+    _CARRIER = carrier
 
 
 def all_reduce(t):
@@ -31,25 +35,18 @@ def all_reduce(t):
     direct = _comm.active()
     if direct is not None and direct.usable(t):
         return direct.all_reduce(t)
-    if _staged(t):
-        h = t.cpu()
-        dist.all_reduce(h)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t)
+    if _CARRIER is not None:
+        return _CARRIER.all_reduce(t)
+    dist.all_reduce(t)
     return t
 
 
 def gather_to_rank0(t):
     """Rank 0 receives every rank's tensor (list in rank order), the others None
     (reference: layers/embed_head.py:180-192)."""
-    rank0 = tp_rank() == 0
-    if _staged(t):
-        h = t.cpu()
-        parts = [torch.empty_like(h) for _ in range(tp_size())] if rank0 else None
-        dist.gather(h, parts, 0)
-        return [p.to(t.device) for p in parts] if rank0 else None
-    parts = [torch.empty_like(t) for _ in range(tp_size())] if rank0 else None
+    if _CARRIER is not None:
+        return _CARRIER.gather_to_rank0(t)
+    parts = [torch.empty_like(t) for _ in range(tp_size())] if tp_rank() == 0 else None
     dist.gather(t, parts, 0)
     return parts
 

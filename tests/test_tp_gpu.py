@@ -1,8 +1,9 @@
 """Tensor-parallel engine path through the HIP kernels, rehearsed on ONE GPU: two rank processes
-share cuda:0 (Config.shared_device). The decode-sized all-reduces run on the direct IPC path
+share cuda:0 (Config.device = "cuda:0"). The decode-sized all-reduces run on the direct IPC path
 (lv_comm), exactly as between two GPUs; the process group is "gloo" (RCCL refuses two ranks on one
 device), which carries the IPC handles, the prefill-sized all-reduces and the logits gather staged
-over host memory. Everything but that transport is the production TP=2 path: per-rank head sharding
+over host memory by a test-side carrier (tests/_host_staged.py). Everything but that transport is
+the production TP=2 path: per-rank head sharding
 (32/8 -> 16/4 q/kv heads, the matrix-core decode kernel), per-rank KV caches with global block
 ids, the shared-memory step RPC, the masked embedding all-reduce and the logits gather
 (reference: engine/model_runner.py:116-180, layers/linear.py:240-395, layers/embed_head.py:18-197).
@@ -35,10 +36,13 @@ def _worker(rank, world, port, event, out_path, enforce_eager=True):
     from light_vllm_amd.engine.scheduler import Scheduler
     from light_vllm_amd.engine.sequence import Sequence
     from light_vllm_amd.sampling_params import SamplingParams
+    from light_vllm_amd.layers import tp
+    from tests._host_staged import HostStagedCarrier
+    tp.set_carrier(HostStagedCarrier())
     golden = load_golden("e2e_prefix_gqa4.json")
     cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=64, max_num_seqs=16,
                  enforce_eager=enforce_eager, random_seed=golden["seed"], tensor_parallel_size=world,
-                 dist_backend="gloo", shared_device=True, dist_init_method=f"tcp://127.0.0.1:{port}")
+                 dist_backend="gloo", device="cuda:0", dist_init_method=f"tcp://127.0.0.1:{port}")
     if rank != 0:
         ModelRunner(cfg, rank, event)          # serves the step RPC until "exit"
         return
@@ -97,10 +101,13 @@ def _worker_lagcopy(rank, world, port, event, out_path):
     from light_vllm_amd.engine.scheduler import Scheduler
     from light_vllm_amd.engine.sequence import Sequence
     from light_vllm_amd.sampling_params import SamplingParams
+    from light_vllm_amd.layers import tp
+    from tests._host_staged import HostStagedCarrier
+    tp.set_carrier(HostStagedCarrier())
     golden = load_golden("e2e_lagcopy_256.json")
     cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=24, max_num_seqs=16, max_model_len=2048,
                  enforce_eager=False, random_seed=golden["seed"], random_kind="lagcopy", tensor_parallel_size=world,
-                 dist_backend="gloo", shared_device=True, dist_init_method=f"tcp://127.0.0.1:{port}")
+                 dist_backend="gloo", device="cuda:0", dist_init_method=f"tcp://127.0.0.1:{port}")
     if rank != 0:
         ModelRunner(cfg, rank, event)
         return
