@@ -103,6 +103,31 @@ def long_prompts():
     return [torch.randint(0, 151936, (n,), generator=g).tolist() for n in (2100, 2500)]
 
 
+def g8_config(layers=4):
+    """Per-rank head geometry of Qwen3-32B under TP = 8 (8 query heads on 1 kv head of 128) on a
+    narrow residual stream."""
+    cfg = qwen3_0p6b_config(layers)
+    cfg.num_attention_heads = 8
+    cfg.num_key_value_heads = 1
+    return cfg
+
+
+def mixed_prompts():
+    """BASELINE config 5 in miniature: six requests, four of them sharing a 1024-token prefix (whole
+    or in part), arriving in two waves, so prefill steps (with prefix-cache hits on blocks that
+    running sequences still hold) interleave with decode steps of the earlier requests.
+    Returns (prompts, arrivals): arrivals[step] = indices submitted before that step is scheduled."""
+    g = torch.Generator().manual_seed(80)
+
+    def rnd(n):
+        return torch.randint(0, 151936, (n,), generator=g).tolist()
+
+    base = rnd(1024)
+    prompts = [base + rnd(150), base + rnd(40), rnd(700),             # first wave
+               base + rnd(300), rnd(300), base[:512] + rnd(100)]      # second wave, four decode steps later
+    return prompts, {0: [0, 1, 2], 5: [3, 4, 5]}
+
+
 def lagcopy_prompts():
     """Four prompts of 300 / 513 / 700 / 1024 random tokens for the lag-copy checkpoint
     (light_vllm_amd.utils.loader.lagcopy_checkpoint): all longer than its 257-position lag, of
@@ -122,8 +147,8 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "e2e_config1.json"))
-    ap.add_argument("--shape", default="0.6b", choices=["0.6b", "gqa4"])
-    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix", "long", "lagcopy"])
+    ap.add_argument("--shape", default="0.6b", choices=["0.6b", "gqa4", "g8"])
+    ap.add_argument("--scenario", default="config1", choices=["config1", "prefix", "long", "lagcopy", "mixed"])
     ap.add_argument("--weights", default="normal", choices=["normal", "lagcopy"])
     ap.add_argument("--min-gap-ulps", type=float, default=0.0,
                     help="fail unless the top-2 logit gap of every recorded step is at least this many bf16 steps")
@@ -141,14 +166,14 @@ def main():
     from lightvllm.utils.context import reset_context, set_context
     from light_vllm_amd.utils.loader import load_random
 
-    hf = qwen3_0p6b_config(args.layers) if args.shape == "0.6b" else gqa4_config(args.layers)
+    hf = {"0.6b": qwen3_0p6b_config, "gqa4": gqa4_config, "g8": g8_config}[args.shape](args.layers)
     torch.set_default_dtype(torch.bfloat16)
     model = Qwen3ForCausalLM(hf)
     torch.set_default_dtype(torch.float32)
     load_random(model, hf, args.seed, kind=args.weights)
     sampler = Sampler()
 
-    block_size, num_blocks = 256, (24 if args.scenario in ("long", "lagcopy") else 16)
+    block_size, num_blocks = 256, (24 if args.scenario in ("long", "lagcopy", "mixed") else 16)
     kv = torch.zeros(2, hf.num_hidden_layers, num_blocks, block_size, hf.num_key_value_heads, hf.head_dim,
                      dtype=torch.bfloat16)
     layer_id = 0
@@ -161,12 +186,17 @@ def main():
                           num_kvcache_blocks=num_blocks, kvcache_block_size=block_size)
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=args.steps, ignore_eos=True)
-    prompts = {"config1": config1_prompts, "prefix": prefix_prompts, "long": long_prompts,
-               "lagcopy": lagcopy_prompts}[args.scenario]()
+    arrivals = None
+    if args.scenario == "mixed":
+        prompts, arrivals = mixed_prompts()
+    else:
+        prompts = {"config1": config1_prompts, "prefix": prefix_prompts, "long": long_prompts,
+                   "lagcopy": lagcopy_prompts}[args.scenario]()
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
-    for s in seqs:
-        sch.add(s)
+    if arrivals is None:
+        for s in seqs:
+            sch.add(s)
 
     # step inputs: the restated prepare_* of oracle/host_oracle.py, as CPU tensors
     def prepare_prefill(batch):
@@ -188,7 +218,9 @@ def main():
     cached_at_prefill = [0] * len(seqs)
     t0 = time.time()
     with torch.inference_mode():
-        while not sch.is_finished():
+        while not sch.is_finished() or (arrivals and max(arrivals) >= len(steps)):
+            for j in (arrivals or {}).get(len(steps), []):
+                sch.add(seqs[j])
             batch, is_prefill = sch.schedule()
             if is_prefill:
                 for s_ in batch:
@@ -212,8 +244,10 @@ def main():
     if worst[0] < args.min_gap_ulps:
         raise SystemExit(f"gap {worst[0]:.1f} < required {args.min_gap_ulps} bf16 steps: not written")
 
-    out = {"model": "Qwen3-0.6B shapes, random init" if args.shape == "0.6b" else
-                    "Qwen3-8B head geometry (32q/8kv x 128) on hidden 1024, random init",
+    out = {"model": {"0.6b": "Qwen3-0.6B shapes, random init",
+                     "gqa4": "Qwen3-8B head geometry (32q/8kv x 128) on hidden 1024, random init",
+                     "g8": "Qwen3-32B TP=8 per-rank head geometry (8q/1kv x 128) on hidden 1024, random init"}[args.shape],
+           "arrivals": None if arrivals is None else {str(k): v for k, v in arrivals.items()},
            "shape": args.shape, "scenario": args.scenario,
            "prompts": prompts if args.scenario != "config1" else None,
            "cached_tokens_at_prefill": [int(x) for x in cached_at_prefill],

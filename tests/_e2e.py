@@ -32,8 +32,17 @@ def gqa4_config(layers=4, dtype=torch.bfloat16):
     return cfg
 
 
+def g8_config(layers=4, dtype=torch.bfloat16):
+    """Per-rank head geometry of Qwen3-32B under TP = 8 (8 q / 1 kv head) on the 0.6B residual width."""
+    cfg = qwen3_0p6b_config(layers, dtype)
+    cfg.num_attention_heads = 8
+    cfg.num_key_value_heads = 1
+    return cfg
+
+
 def golden_config(golden, dtype=torch.bfloat16):
-    return gqa4_config(golden["layers"], dtype) if golden.get("shape") == "gqa4" else qwen3_0p6b_config(golden["layers"], dtype)
+    make = {"gqa4": gqa4_config, "g8": g8_config}.get(golden.get("shape"), qwen3_0p6b_config)
+    return make(golden["layers"], dtype)
 
 
 def golden_prompts(golden):
@@ -77,10 +86,14 @@ def replay(golden, runner, scheduler, tie_ulps, max_steps=None):
     prompts = golden_prompts(golden)
     seqs = [Sequence(p, sp) for p in prompts]
     index = {id(s): i for i, s in enumerate(seqs)}
-    for s in seqs:
-        scheduler.add(s)
+    arrivals = golden.get("arrivals")       # {step: [sequence indices submitted before that step]}
+    if not arrivals:
+        for s in seqs:
+            scheduler.add(s)
     compared, soft, hard, max_dev = 0, [], [], 0.0
     for step_no, rec in enumerate(golden["steps"][:max_steps]):
+        for j in (arrivals or {}).get(str(step_no), []):
+            scheduler.add(seqs[j])
         batch, is_prefill = scheduler.schedule()
         assert is_prefill == rec["prefill"], f"step {step_no}: phase differs"
         assert [index[id(s)] for s in batch] == rec["seqs"], f"step {step_no}: batch differs"

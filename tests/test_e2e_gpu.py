@@ -113,6 +113,32 @@ def test_prefix_cache_scenario_gqa4(gpu, enforce_eager):
 
 
 @pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
+def test_mixed_prefill_decode_prefix_scenario_g8(gpu, enforce_eager):
+    """BASELINE config 5 in miniature at its per-rank head geometry (Qwen3-32B under TP = 8: 8 q / 1
+    kv head per rank, the matrix-core decode kernel at group size 8): six requests in two waves,
+    four of them sharing a 1024-token prefix. The second wave's prefill hits blocks that running
+    sequences still hold (cached tokens [0, 1024, 0, 1024, 0, 512], as the reference's BlockManager
+    decides), takes the paged-prefix prefill path between decode steps, and the batch then decodes
+    with six sequences of different ages; teacher-forced and tie-aware against the reference
+    stack's run."""
+    from light_vllm_amd.config import Config
+    from light_vllm_amd.engine.model_runner import ModelRunner
+    from light_vllm_amd.engine.scheduler import Scheduler
+    from tests._e2e import golden_config
+    golden = load_golden("e2e_mixed_g8.json")
+    cfg = Config(None, hf_config=golden_config(golden), num_kvcache_blocks=64, max_num_seqs=16, max_model_len=2048,
+                 enforce_eager=enforce_eager, random_seed=golden["seed"])
+    runner = ModelRunner(cfg, 0, [])
+    compared, soft, hard, max_dev = replay(golden, runner, Scheduler(cfg), tie_ulps=TIE_ULPS)
+    print(f"compared {compared} tokens, max top-5 logit deviation {max_dev:.4f}, tie flips {soft}, hard mismatches {hard}")
+    runner.exit()
+    assert compared == 6 * golden["max_tokens"]
+    assert not hard, f"token mismatches outside ties: {hard}"
+    assert max_dev <= MAX_LOGIT_DEV, f"logit deviation {max_dev}"
+    assert len(soft) <= compared // 10, f"too many tie flips: {soft}"
+
+
+@pytest.mark.parametrize("enforce_eager", [True, False], ids=["eager", "hipgraph"])
 def test_long_prompt_scenario_gqa4(gpu, enforce_eager):
     """Prompts of 2100 and 2500 tokens in one prefill batch: the prefill call takes the kernel the
     library chooses for long prompts (the phase-locked 8-wave kernel), decode then reads 9-10

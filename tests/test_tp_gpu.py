@@ -111,7 +111,7 @@ def _worker_lagcopy(rank, world, port, event, out_path):
     if rank != 0:
         ModelRunner(cfg, rank, event)
         return
-    runner = ModelRunner(cfg, 0, [event])
+    runner = ModelRunner(cfg, 0, list(event))
     sch = Scheduler(cfg)
     sp = SamplingParams(temperature=0.0, max_tokens=64, ignore_eos=True)
     seqs = [Sequence(p, sp) for p in golden["prompts"]]
@@ -125,16 +125,19 @@ def _worker_lagcopy(rank, world, port, event, out_path):
         json.dump([list(s.completion_token_ids) for s in seqs], f)
 
 
-def test_tp2_free_running_tokens_identical(gpu, tmp_path):
-    """TP = 2 changes the summation order of every all-reduce, yet the lag-copy fixture's margins
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_free_running_tokens_identical(gpu, tmp_path, world):
+    """TP = 2 / 4 (per-rank 8q/4kv and 4q/2kv heads, hipGraph decode with 57 direct all-reduces per
+    forward) changes the summation order of every all-reduce, yet the lag-copy fixture's margins
     (more than 140 bf16 steps at every step) make the greedy tokens independent of it: the first 64
     generated tokens of each sequence must equal the reference stack's TP = 1 run exactly."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    event = ctx.Event()
-    out_path = os.path.join(str(tmp_path), "tp2_lagcopy.json")
+    out_path = os.path.join(str(tmp_path), "tp_lagcopy.json")
     port = _free_port()
-    procs = [ctx.Process(target=_worker_lagcopy, args=(r, 2, port, event, out_path)) for r in range(2)]
+    events = [ctx.Event() for _ in range(world - 1)]
+    procs = [ctx.Process(target=_worker_lagcopy, args=(r, world, port, events if r == 0 else events[r - 1], out_path))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

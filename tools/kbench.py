@@ -102,8 +102,19 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
         ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out)
 
     # matrix-bound kernels run ~19 % slower for the first ~10 ms after an idle GPU (clock ramp):
-    # 20 untimed launches first, so that the timed ones see the clocks a busy engine has
-    t = timeit(fn, iters=iters, warmup=20)
+    # at least 20 untimed launches and 25 ms of them first, so that the timed ones see the clocks a
+    # busy engine has
+    import time
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_warm = 0
+    while n_warm < 20 or time.perf_counter() - t0 < 0.025:
+        fn()
+        n_warm += 1
+        if n_warm % 10 == 0:
+            torch.cuda.synchronize()
+    t = timeit(fn, iters=iters, warmup=2)
     flops = sum(4 * Hq * D * (L * L - L * (L - 1) // 2) for L in lens)
     return dict(kind="prefill", data=data, iters=iters, lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
@@ -112,10 +123,14 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="decode")
+    ap.add_argument("--lib", default=None, help="another build of liblvattn.so to measure (A/B runs)")
     ap.add_argument("--decode-kernel", default="auto", choices=list(ops.DECODE_KERNELS))
     ap.add_argument("--prefill-kernel", default="auto", choices=list(ops.PREFILL_KERNELS))
     args = ap.parse_args()
     ops.DEFAULT_KERNEL.update(decode=args.decode_kernel, prefill=args.prefill_kernel)
+    if args.lib:
+        from light_vllm_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     rows = []
     if args.what in ("decode", "all"):
         for (Hq, Hkv) in [(16, 8), (32, 8), (64, 8)]:
@@ -150,6 +165,14 @@ def main():
             rows.append(prefill_case(lens, Hq, Hkv))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
+    if args.what == "decode_8b":         # the north-star shapes and their TP shards, uniform and ragged
+        for (Hq, Hkv) in [(32, 8), (16, 4), (8, 2), (4, 1), (64, 8), (8, 1)]:
+            rows.append(decode_case(256, 1024, Hq, Hkv, graph=True))
+        rows.append(decode_case(256, 1024, 32, 8, ragged=True, ordered=True, graph=True))
+        rows.append(decode_case(256, 4096, 32, 8, ragged=True, ordered=True, graph=True))
+        rows.append(decode_case(32, 32768, 32, 8, graph=True))
+        rows.append(decode_case(32, 32768, 4, 1, graph=True))
+        rows.append(decode_case(64, 4096, 32, 8, graph=True))
     if args.what == "decode_g8":
         rows.append(decode_case(256, 1024, 64, 8))
     if args.what == "decode_ragged":
