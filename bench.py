@@ -238,6 +238,24 @@ def prefill_leg(ops, dev, n, iters=50, warmup=20):
             "bound": "mfma", "flops_per_launch": flops}
 
 
+def sustained_mfma_peak():
+    """tools/mfma_peak (built by __graft_entry__.build): every SIMD issues bf16 MFMAs back to back
+    from registers for ~50 ms, operands random like attention's. What it reaches is the matrix rate
+    the chip sustains at the clock its power management allows under that load, the practical
+    ceiling under the 2.5 PFLOP/s the spec quotes at 2.4 GHz. None when the tool is not built."""
+    exe = os.path.join(ROOT, "tools", "mfma_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "2", "1"], capture_output=True, text=True, timeout=60).stdout
+        for line in out.splitlines():
+            if line.startswith("RESULT "):
+                return json.loads(line[len("RESULT "):])
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        pass
+    return None
+
+
 def time_all_reduce(fn, x, iters=50):
     for _ in range(5):
         fn(x)
@@ -461,6 +479,10 @@ def main():
     if rank == 0 and not args.no_aux:
         try:
             result["prefill"] = prefill_leg(ops, dev, n)
+            burn = sustained_mfma_peak()
+            if burn:
+                result["prefill"]["sustained_mfma"] = burn
+                result["prefill"]["frac_of_sustained"] = round(result["prefill"]["tflops"] / burn["tflops"], 4)
         except Exception as exc:   # reported, never fatal for the headline number
             result["prefill"] = {"error": repr(exc)[:300]}
     if n == 1 and not args.no_aux:
