@@ -21,9 +21,11 @@ ALGORITHMS = {"auto": 0, "one_shot": 1, "two_shot": 2}
 
 
 class DirectAllReduce:
-    """This rank's end of an lv_comm communicator on `device`."""
+    """This rank's end of an lv_comm communicator on `device`. Construction is local (allocate the
+    buffers, export the handle); `connect` maps the peers; the exchange of the handles in between
+    is the caller's (create_for_group does it over a torch.distributed group)."""
 
-    def __init__(self, device: torch.device, rank: int, world_size: int, timeout_ms: int = 0, group=None):
+    def __init__(self, device: torch.device, rank: int, world_size: int, timeout_ms: int = 0):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self._lib = _lib.load()
@@ -32,11 +34,13 @@ class DirectAllReduce:
             _lib.check(self._lib.lv_comm_create(rank, world_size, timeout_ms, ctypes.byref(self._comm)), "lv_comm_create")
             mine = ctypes.create_string_buffer(HANDLE_BYTES)
             _lib.check(self._lib.lv_comm_get_handle(self._comm, mine), "lv_comm_get_handle")
-            blobs = [None] * world_size
-            dist.all_gather_object(blobs, bytes(mine.raw), group=group)
-            assert all(isinstance(b, bytes) and len(b) == HANDLE_BYTES for b in blobs)
-            _lib.check(self._lib.lv_comm_connect(self._comm, b"".join(blobs)), "lv_comm_connect")
-        dist.barrier(group=group)          # every rank has mapped every peer before the first use
+        self.handle = bytes(mine.raw)
+
+    def connect(self, handles) -> None:
+        """handles: every rank's `handle` in rank order."""
+        assert len(handles) == self.world_size and all(isinstance(h, bytes) and len(h) == HANDLE_BYTES for h in handles)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.lv_comm_connect(self._comm, b"".join(handles)), "lv_comm_connect")
 
     def usable(self, t: torch.Tensor) -> bool:
         nbytes = t.numel() * t.element_size()
@@ -65,28 +69,48 @@ class DirectAllReduce:
 
 
 def create_for_group(device: torch.device, timeout_ms: int = 0, group=None) -> Optional[DirectAllReduce]:
-    """Collective over `group`: every rank tries to build its end; the communicator is kept only if
-    every rank succeeded (IPC can be unavailable, e.g. ranks in different containers), otherwise all
-    ranks drop it together and the callers stay on RCCL. Returns None then."""
+    """Collective over `group`: every rank builds its end, the handles travel through the group, every
+    rank maps its peers. Each local step is followed by an exchange of its outcome, so that a rank
+    on which a step fails (IPC can be unavailable, e.g. ranks in different containers) never leaves
+    the others waiting in a different collective: all ranks keep the communicator or all drop it
+    together and stay on torch.distributed. Returns None then."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def agree(ok: bool, payload):
+        """all-gather (ok, payload); returns (everyone ok, payloads in rank order)."""
+        got = [None] * world
+        dist.all_gather_object(got, (ok, payload), group=group)
+        return all(g[0] for g in got), [g[1] for g in got]
+
+    def give_up(comm, reasons):
+        if comm is not None:
+            comm.close()
+        if rank == 0:
+            print("direct all-reduce unavailable, staying on torch.distributed:",
+                  "; ".join(f"rank {r}: {m}" for r, m in enumerate(reasons) if isinstance(m, str) and m), flush=True)
+        return None
+
     comm, err = None, ""
-    ok = False
     if 2 <= world <= 8:
         try:
-            comm = DirectAllReduce(device, rank, world, timeout_ms, group)
-            ok = True
+            comm = DirectAllReduce(device, rank, world, timeout_ms)
         except Exception as exc:      # noqa: BLE001 - any failure means "not available on this rank"
             err = repr(exc)
-    flags = [None] * world
-    dist.all_gather_object(flags, (ok, err), group=group)
-    if all(f[0] for f in flags):
-        return comm
-    if comm is not None:
-        comm.close()
-    if rank == 0:
-        print("direct all-reduce unavailable, staying on torch.distributed:",
-              "; ".join(f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0]), flush=True)
-    return None
+    else:
+        err = f"{world} ranks (2..8 supported)"
+    ok, payloads = agree(comm is not None, comm.handle if comm is not None else err)
+    if not ok:
+        return give_up(comm, payloads)
+    err = ""
+    try:
+        comm.connect(payloads)
+    except Exception as exc:          # noqa: BLE001
+        err = repr(exc)
+    ok, reasons = agree(not err, err)
+    if not ok:
+        return give_up(comm, reasons)
+    dist.barrier(group=group)         # every rank has mapped every peer before the first use
+    return comm
 
 
 _ACTIVE: Optional[DirectAllReduce] = None

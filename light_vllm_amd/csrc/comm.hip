@@ -268,6 +268,22 @@ int lv_comm_connect(lv_comm_t* c, const void* all_handles) {
     }
     c->base[r] = static_cast<unsigned char*>(ptr);
   }
+  // Touch every mapping from the host before any kernel does: a mapping this device cannot reach
+  // then fails here with an error code instead of faulting a kernel.
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    uint32_t probe = 0;
+    hipError_t e = hipMemcpy(&probe, c->base[r], sizeof(probe), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      for (int q = 0; q < c->world; ++q)
+        if (q != c->rank && c->base[q]) {
+          (void)hipIpcCloseMemHandle(c->base[q]);
+          c->base[q] = nullptr;
+        }
+      return fail(LV_ERR_COMM, "comm_connect: rank %d's buffer is mapped but not readable from device %d: %s", r,
+                  c->device, hipGetErrorString(e));
+    }
+  }
   c->connected = true;
   return LV_OK;
 }

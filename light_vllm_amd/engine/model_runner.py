@@ -70,7 +70,9 @@ class ModelRunner:
         self.direct_comm = None
         if self.world_size > 1 and self.on_gpu and config.direct_all_reduce:
             from .. import comm as lvcomm
-            self.direct_comm = lvcomm.create_for_group(self.device)
+            # a minute of grace: ranks reach their first all-reduce (the warmup prefill) as unevenly
+            # as their weights load
+            self.direct_comm = lvcomm.create_for_group(self.device, timeout_ms=60000)
             lvcomm.install(self.direct_comm)
 
         default_dtype = torch.get_default_dtype()
@@ -88,6 +90,8 @@ class ModelRunner:
                 load_model(self.model, config.model)
             self.sampler = Sampler()
             self.kv_cache = None
+            if self.world_size > 1:
+                dist.barrier()          # every rank has its weights: the first collective starts together
             self.warmup_model()
             self.allocate_kv_cache()
             if not self.enforce_eager:

@@ -100,3 +100,18 @@ def test_ops_refuse_cpu_tensors():
     c = torch.zeros(1, 256, 8, 128, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.store_kvcache(x, x, c, c, torch.zeros(1, dtype=torch.int32))
+
+
+def test_comm_argument_validation_without_a_device():
+    """The communicator's entry points reject bad arguments on the host before any HIP call."""
+    from light_vllm_amd import _lib
+    lib = _lib.load()
+    comm = ctypes.c_void_p()
+    assert lib.lv_comm_create(5, 2, 0, ctypes.byref(comm)) == -1 and not comm.value       # rank outside the world
+    assert lib.lv_comm_create(0, 9, 0, ctypes.byref(comm)) == -1 and b"2..8" in lib.lv_last_error()
+    assert lib.lv_comm_create(0, 2, -1, ctypes.byref(comm)) == -1
+    assert lib.lv_comm_create(0, 2, 0, None) == -1
+    assert lib.lv_comm_all_reduce(None, None, 8, 0, None) == -1
+    assert lib.lv_comm_get_handle(None, None) == -1 and lib.lv_comm_connect(None, None) == -1
+    assert lib.lv_comm_failed(None) == 1 and lib.lv_comm_destroy(None) == 0
+    assert lib.lv_error_string(-5) == b"communicator failure"
