@@ -46,6 +46,7 @@ class ModelRunner:
         self.config = config
         hf_config = config.hf_config
         self.block_size = config.kvcache_block_size
+        self.max_position = hf_config.max_position_embeddings
         Sequence.set_block_size(self.block_size)
         self.enforce_eager = config.enforce_eager
         self.world_size = config.tensor_parallel_size
@@ -232,8 +233,8 @@ class ModelRunner:
     def _check_positions(self, last_position: int) -> None:
         """Positions index the rotary table (max_position_embeddings rows). The fused kernel clamps
         instead of faulting, so the range is enforced here, where the lengths are known."""
-        limit = self.config.hf_config.max_position_embeddings
-        if last_position >= limit:
+        limit = getattr(self, "max_position", None)     # None: a bare runner built for its step-input builders
+        if limit is not None and last_position >= limit:
             raise IndexError(f"position {last_position} is outside the rotary table of {limit} rows "
                              "(sequence longer than max_position_embeddings)")
 

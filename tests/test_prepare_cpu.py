@@ -119,3 +119,27 @@ def test_random_batches_match_restatement():
     finally:
         Sequence.block_size = 256
         reset_context()
+
+
+def test_positions_beyond_the_rotary_table_are_refused():
+    """The fused norm/RoPE kernel clamps positions instead of faulting, so the runner checks the
+    range where the lengths are known. Decode feeds position len(seq) (model_runner.py:405)."""
+    import pytest
+    Sequence.block_size = 4
+    try:
+        r = _runner(4)
+        r.max_position = 8
+        s = Sequence(list(range(7)))
+        s.block_table = [0, 1]
+        r.prepare_decode([s])                       # position 7: the last row of the table
+        reset_context()
+        s.append_token(1)
+        with pytest.raises(IndexError, match="rotary table"):
+            r.prepare_decode([s])                   # position 8
+        long = Sequence(list(range(9)))
+        long.block_table = [0, 1, 2]
+        with pytest.raises(IndexError, match="rotary table"):
+            r.prepare_prefill([long])               # positions 0..8
+    finally:
+        Sequence.block_size = 256
+        reset_context()
