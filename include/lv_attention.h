@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 6
+#define LV_ABI_VERSION 7
 
 /* kernel_hint of lv_decode_attn: which of the two decode kernels serves the call. */
 #define LV_DECODE_KERNEL_AUTO 0   /* by num_heads / num_kv_heads: vector-ALU for 1-2, matrix-core for 3-8 */
@@ -170,6 +170,14 @@ int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_str
  * kernel_hint: LV_PREFILL_KERNEL_AUTO, or one of the LV_PREFILL_KERNEL_* values to force that
  * kernel (every one of them computes the same function; the choice is a performance matter and
  * what the parity tests iterate over). No counterpart in the reference call.
+ * num_splits / workspace / total_q: KV splits of every query tile (flash-decoding for prefill): with
+ *   few query rows against a long context (a prefix-cache hit, a short batch) one workgroup per
+ *   query tile would walk the whole context alone; n > 1 cuts each tile's keys into n runs, whose
+ *   fp32 partial outputs go through `workspace` (>= lv_prefill_workspace_bytes, 16-byte aligned) to a
+ *   merge pass. 0 = library heuristic (lv_prefill_num_splits; it stays at one pass when no
+ *   sufficient workspace is given), 1 = one pass, up to 32. total_q = rows of q (needed with
+ *   num_splits != 1). Results agree with the one-pass kernels to bf16 rounding (different
+ *   summation order). The workspace rule of lv_decode_attn applies: one stream per workspace.
  */
 int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
@@ -177,7 +185,14 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int batch, int max_seqlen_q, int max_seqlen_k,
                     const int32_t* block_table, int block_table_stride, int block_size,
                     int num_heads, int num_kv_heads, int head_dim, float scale,
+                    int64_t total_q, void* workspace, size_t workspace_bytes, int num_splits,
                     int kernel_hint, lv_stream_t stream);
+
+/* Split count lv_prefill_attn uses for num_splits == 0 on these static shapes. */
+int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads);
+
+/* Bytes of workspace lv_prefill_attn needs for (total_q, num_heads, num_splits); 0 for <= 1 split. */
+size_t lv_prefill_workspace_bytes(int64_t total_q, int num_heads, int head_dim, int num_splits);
 
 /*
  * Split count lv_decode_attn will use when called with num_splits == 0, for these static

@@ -41,7 +41,7 @@ extern "C" {
 
 #define LV_COMM_HANDLE_BYTES 64           /* one HIP IPC memory handle */
 #define LV_COMM_MAX_RANKS 8
-#define LV_COMM_MAX_BYTES (4u << 20)      /* largest message lv_comm_all_reduce takes */
+#define LV_COMM_MAX_BYTES (8u << 20)      /* largest message lv_comm_all_reduce takes: [512, 8192] bf16 */
 
 /* algorithm of lv_comm_all_reduce */
 #define LV_COMM_ALGO_AUTO 0               /* by message size and rank count */

@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 from . import _lib
 
-MAX_BYTES = 4 << 20          # LV_COMM_MAX_BYTES
+MAX_BYTES = 8 << 20          # LV_COMM_MAX_BYTES
 HANDLE_BYTES = 64            # LV_COMM_HANDLE_BYTES
 ALGORITHMS = {"auto": 0, "one_shot": 1, "two_shot": 2}
 
@@ -51,7 +51,7 @@ class DirectAllReduce:
         """In-place bf16 sum over the ranks (fp32 accumulation in rank order, identical bits on
         every rank). Stream-ordered on torch's current stream; capturable into a hipGraph.
         algorithm: "auto", "one_shot" or "two_shot" (same result; the same on every rank)."""
-        assert self.usable(t), "direct all-reduce: contiguous bf16 GPU tensor of at most 4 MiB, 16-byte multiple"
+        assert self.usable(t), "direct all-reduce: contiguous bf16 GPU tensor of at most 8 MiB, 16-byte multiple"
         with torch.cuda.device(self.device):
             rc = self._lib.lv_comm_all_reduce(self._comm, t.data_ptr(), t.numel(), ALGORITHMS[algorithm],
                                               torch.cuda.current_stream(self.device).cuda_stream)

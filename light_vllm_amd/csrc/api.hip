@@ -58,6 +58,28 @@ static int heuristic_splits(int batch, int num_kv_heads, int max_blocks_per_seq,
   return n < 1 ? 1 : static_cast<int>(n);
 }
 
+constexpr int kMaxPrefillSplits = 32;
+
+// KV splits of a prefill launch, from its static shape alone (lengths live on the device): none
+// while the query tiles by themselves give more than one workgroup per CU or the context is short;
+// otherwise enough runs to reach about two workgroups per CU, each at least eight 64-key tiles
+// long. The case it is for: few new tokens against a long cached prefix (a prefix-cache hit, a
+// short batch), where one workgroup per query tile would walk the whole context alone. Fitted to
+// tools/kbench.py --what prefill_prefix (forced 1/2/4/8 runs on seven shapes): 8 x 100 new tokens
+// on 4096 cached, 8q/1kv: 107 -> 39 us; 1 x 100 on 32000: 760 -> 44 us; 256 workgroups (8 x 100 on
+// 4096, 32q/8kv): 109 -> 95 us with 2 runs, slower from 8; 144 workgroups of 21 tiles: no gain.
+static int prefill_heuristic_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads) {
+  if (batch <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || num_heads <= 0) return 1;
+  const int bm = max_seqlen_q <= 1024 ? 128 : 256;
+  const int64_t wgs = static_cast<int64_t>((max_seqlen_q + bm - 1) / bm) * num_heads * batch;
+  const int ktiles = (max_seqlen_k + 63) / 64;
+  if (wgs > 256) return 1;
+  int64_t n = (512 + wgs - 1) / wgs;
+  if (n > ktiles / 8) n = ktiles / 8;
+  if (n > kMaxPrefillSplits) n = kMaxPrefillSplits;
+  return n < 1 ? 1 : static_cast<int>(n);
+}
+
 }  // namespace lv
 
 // Split-KV scratch of lv_decode_attn_static: a device array of the code object, so that entry
@@ -232,7 +254,8 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
                     const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch,
                     int max_seqlen_q, int max_seqlen_k, const int32_t* block_table,
                     int block_table_stride, int block_size, int num_heads, int num_kv_heads,
-                    int head_dim, float scale, int kernel_hint, lv_stream_t stream) {
+                    int head_dim, float scale, int64_t total_q, void* workspace, size_t workspace_bytes,
+                    int num_splits, int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || num_heads <= 0 || num_kv_heads <= 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "prefill: head_dim %d != 128", head_dim);
@@ -277,8 +300,37 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
   p.num_heads = num_heads;
   p.num_kv_heads = num_kv_heads;
   p.kernel_hint = kernel_hint;
+  if (num_splits < 0 || num_splits > kMaxPrefillSplits)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: num_splits %d not in 0..%d", num_splits, kMaxPrefillSplits);
+  int nsplit = num_splits == 0 ? prefill_heuristic_splits(batch, max_seqlen_q, max_seqlen_k, num_heads) : num_splits;
+  // the automatic choice falls back to one pass when the caller brought no workspace for it
+  if (num_splits == 0 && nsplit > 1 &&
+      (!workspace || workspace_bytes < lv_prefill_workspace_bytes(total_q, num_heads, head_dim, nsplit)))
+    nsplit = 1;
+  p.nsplit = nsplit;
+  p.ws_o = nullptr;
+  p.ws_ml = nullptr;
+  p.total_q = total_q;
+  if (nsplit > 1) {
+    if (total_q <= 0) return fail(LV_ERR_INVALID_ARGUMENT, "prefill: total_q must be given with num_splits > 1");
+    const size_t need = lv_prefill_workspace_bytes(total_q, num_heads, head_dim, nsplit);
+    if (!workspace || workspace_bytes < need || !aligned16(workspace))
+      return fail(LV_ERR_WORKSPACE, "prefill: workspace %zu B < %zu B needed for %d splits (or misaligned)",
+                  workspace_bytes, need, nsplit);
+    p.ws_o = static_cast<float*>(workspace);
+    p.ws_ml = p.ws_o + static_cast<size_t>(total_q) * num_heads * nsplit * kHeadDim;
+  }
   p.scale_log2e = scale * kLog2e;
   return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
+}
+
+int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads) {
+  return prefill_heuristic_splits(batch, max_seqlen_q, max_seqlen_k, num_heads);
+}
+
+size_t lv_prefill_workspace_bytes(int64_t total_q, int num_heads, int head_dim, int num_splits) {
+  if (total_q <= 0 || num_heads <= 0 || head_dim != kHeadDim || num_splits <= 1) return 0;
+  return static_cast<size_t>(total_q) * num_heads * num_splits * (kHeadDim + 2) * sizeof(float);
 }
 
 int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {

@@ -32,6 +32,10 @@ struct PrefillParams {
   const int32_t* block_table;  // nullptr = packed K/V
   int bt_stride, block_size, batch, max_seqlen_q, num_heads, num_kv_heads;
   int kernel_hint;             // LV_PREFILL_KERNEL_* (| LV_PREFILL_STAGE_DMA)
+  int nsplit;                  // KV splits per query tile (1: none); > 1 needs the workspace below
+  float* ws_o;                 // [total_q, Hq, nsplit, 128] unnormalised partial outputs
+  float* ws_ml;                // [total_q, Hq, nsplit, 2]   (row maximum in log2 units, row sum)
+  int64_t total_q;
   float scale_log2e;
 };
 

@@ -200,10 +200,15 @@ void prefill_attn_kernel(const PrefillParams p) {
   // 2, 1) kv heads all query tiles and query heads that read one (sequence, kv head)'s K/V run on
   // one XCD and share its L2. Then query head within the group, then query tile (heaviest = last
   // rows first), then sequence.
+  // With p.nsplit > 1 the key tiles of a query tile are cut into nsplit runs, one workgroup each
+  // (few query tiles against a long context: a prefix-cached prompt, a short batch); the runs'
+  // unnormalised outputs and (max, sum) go to the workspace and prefill_merge_kernel combines them.
   const int G = p.num_heads / p.num_kv_heads;
   int wg = blockIdx.x;
   const int kvh = wg % p.num_kv_heads;
   wg /= p.num_kv_heads;
+  const int split = wg % p.nsplit;
+  wg /= p.nsplit;
   const int hq = kvh * G + wg % G;
   wg /= G;
   const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
@@ -246,7 +251,10 @@ void prefill_attn_kernel(const PrefillParams p) {
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
-  const int ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
+  const int ntiles_all = max_key >= 0 ? max_key / BN + 1 : 0;
+  // this workgroup's run of key tiles: [t_lo, t_lo + ntiles)
+  const int t_lo = static_cast<int>(static_cast<int64_t>(split) * ntiles_all / p.nsplit);
+  const int ntiles = static_cast<int>(static_cast<int64_t>(split + 1) * ntiles_all / p.nsplit) - t_lo;
 
   // ---- staging: this thread moves chunk st_ch of tile rows st_r + RSTEP*i (i < NST).
   // Address = wave-uniform tile base (scalar registers) + a per-thread byte offset that is the
@@ -540,20 +548,20 @@ void prefill_attn_kernel(const PrefillParams p) {
   // computed; the barrier at the end of the interval (its fence waits for the copies) publishes it.
   if constexpr (DMA) {
     if (ntiles > 0) {
-      stage_dma(0, IntC<0>{});
+      stage_dma(t_lo, IntC<0>{});
       __syncthreads();
     }
     for (int tile = 0; tile < ntiles; tile += 2) {
-      if (tile + 1 < ntiles) stage_dma(tile + 1, IntC<1>{});
+      if (tile + 1 < ntiles) stage_dma(t_lo + tile + 1, IntC<1>{});
       LV_STAMP(3)
-      compute(tile, IntC<0>{});
+      compute(t_lo + tile, IntC<0>{});
       LV_STAMP(1)
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
-        if (tile + 2 < ntiles) stage_dma(tile + 2, IntC<0>{});
+        if (tile + 2 < ntiles) stage_dma(t_lo + tile + 2, IntC<0>{});
         LV_STAMP(3)
-        compute(tile + 1, IntC<1>{});
+        compute(t_lo + tile + 1, IntC<1>{});
         LV_STAMP(1)
         if (!(LV_ABL & 256)) __syncthreads();
         LV_STAMP(0)
@@ -563,26 +571,26 @@ void prefill_attn_kernel(const PrefillParams p) {
   // ---- main loop: tile t is computed from buffer t&1 while tile t+1 sits in registers and tile
     // t+2's loads are in flight; one workgroup barrier per tile.
     if (ntiles > 0) {
-      stage_load(0);
+      stage_load(t_lo);
       stage_write(IntC<0>{});
       __syncthreads();
-      if (ntiles > 1) stage_load(1);
+      if (ntiles > 1) stage_load(t_lo + 1);
     }
     for (int tile = 0; tile < ntiles; tile += 2) {
-      compute(tile, IntC<0>{});
+      compute(t_lo + tile, IntC<0>{});
       if (tile + 1 < ntiles) stage_write(IntC<1>{});
       LV_STAMP(1)
       // the next loads are issued before the barrier: a wave that gets here early spends its
       // wait issuing them, instead of all waves queueing on the memory pipe right after it
-      if (tile + 2 < ntiles) stage_load(tile + 2);
+      if (tile + 2 < ntiles) stage_load(t_lo + tile + 2);
       LV_STAMP(3)
       if (!(LV_ABL & 256)) __syncthreads();
       LV_STAMP(0)
       if (tile + 1 < ntiles) {
-        compute(tile + 1, IntC<1>{});
+        compute(t_lo + tile + 1, IntC<1>{});
         if (tile + 2 < ntiles) stage_write(IntC<0>{});
         LV_STAMP(1)
-        if (tile + 3 < ntiles) stage_load(tile + 3);
+        if (tile + 3 < ntiles) stage_load(t_lo + tile + 3);
         LV_STAMP(3)
         if (!(LV_ABL & 256)) __syncthreads();
         LV_STAMP(0)
@@ -597,6 +605,25 @@ void prefill_attn_kernel(const PrefillParams p) {
     const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     const int my_row = wrow0 + 32 * rb + c;
+    if (p.nsplit > 1) {
+      // this run's share of the row: unnormalised output (this lane's 64 of the 128 columns, in
+      // runs of four: d = 32 dt + 8 rg + 4 h + 0..3) and the (maximum, sum) pair the merge weighs it by
+      if (my_row < Lq) {
+        const int64_t slot = (static_cast<int64_t>(q_start + my_row) * p.num_heads + hq) * p.nsplit + split;
+        float* wo = p.ws_o + slot * kHeadDim + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            *reinterpret_cast<float4*>(wo + 32 * dt + 8 * rg) =
+                make_float4(oacc[rb][dt][4 * rg + 0], oacc[rb][dt][4 * rg + 1], oacc[rb][dt][4 * rg + 2], oacc[rb][dt][4 * rg + 3]);
+        if (h == 0) {
+          p.ws_ml[slot * 2 + 0] = m_run[rb] * cexp;    // -inf for a row that saw no key in this run
+          p.ws_ml[slot * 2 + 1] = l_tot;
+        }
+      }
+      continue;
+    }
     u32x2 w[16];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -1589,6 +1616,41 @@ void prefill_w64_kernel(const PrefillParams p) {
   });
 }
 
+// Combines the nsplit runs of every (query row, head): out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s.
+// 32 lanes per (row, head), four columns each; eight pairs per workgroup.
+__global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restrict__ ws_o,
+                                                            const float* __restrict__ ws_ml,
+                                                            uint16_t* __restrict__ o, int64_t o_stride0,
+                                                            int num_heads, int nsplit, int64_t pairs) {
+  const int64_t pair = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
+  if (pair >= pairs) return;
+  const int ln = threadIdx.x & 31;
+  const int64_t row = pair / num_heads;
+  const int hq = static_cast<int>(pair % num_heads);
+  const int64_t base = pair * nsplit;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ws_ml[(base + s) * 2]);
+  const float Mu = (M == -INFINITY) ? 0.f : M;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float L = 0.f;
+#pragma unroll 4
+  for (int s = 0; s < nsplit; ++s) {
+    const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (base + s) * 2);
+    const float4 v = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + 4 * ln);
+    const float sc = __builtin_amdgcn_exp2f(ml.x - Mu);
+    acc.x += sc * v.x;
+    acc.y += sc * v.y;
+    acc.z += sc * v.z;
+    acc.w += sc * v.w;
+    L += sc * ml.y;
+  }
+  const float inv = L > 0.f ? 1.f / L : 0.f;
+  u32x2 w;
+  w[0] = pack_bf16x2(acc.x * inv, acc.y * inv);
+  w[1] = pack_bf16x2(acc.z * inv, acc.w * inv);
+  *reinterpret_cast<u32x2*>(o + row * o_stride0 + hq * kHeadDim + 4 * ln) = w;
+}
+
 template <bool PAGED>
 static void launch_w64(const PrefillParams& p, hipStream_t stream) {
   const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
@@ -1607,13 +1669,13 @@ template <bool PAGED, int NW, int RB, bool DMA>
 static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
   constexpr int BM = 32 * RB * NW;
   const int64_t qtiles = (p.max_seqlen_q + BM - 1) / BM;
-  const int64_t total = qtiles * p.num_heads * p.batch;
+  const int64_t total = qtiles * p.num_heads * p.batch * p.nsplit;
   hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB, DMA>), dim3(static_cast<unsigned>(total)), dim3(64 * NW), 0,
                      stream, p);
 }
 
 int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
-  if (static_cast<int64_t>((p.max_seqlen_q + 127) / 128) * p.num_heads * p.batch > INT32_MAX)
+  if (static_cast<int64_t>((p.max_seqlen_q + 127) / 128) * p.num_heads * p.batch * p.nsplit > INT32_MAX)
     return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
@@ -1632,6 +1694,9 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
     case LV_PREFILL_KERNEL_W64: cfg = 4; break;
     default: return fail(LV_ERR_INVALID_ARGUMENT, "prefill: kernel_hint %d", p.kernel_hint);
   }
+  // KV splits live in the free-running kernels only: the 8-wave one stands in for the two
+  // long-prompt kernels (within 3-7 % of them unsplit)
+  if (p.nsplit > 1 && (cfg == 2 || cfg == 4)) cfg = 1;
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
   } else if (cfg == 2) {
@@ -1645,6 +1710,13 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "prefill_attn launch: %s", hipGetErrorString(e));
+  if (p.nsplit > 1) {
+    const int64_t pairs = p.total_q * p.num_heads;
+    hipLaunchKernelGGL(prefill_merge_kernel, dim3(static_cast<unsigned>((pairs + 7) / 8)), dim3(256), 0, stream,
+                       p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads, p.nsplit, pairs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "prefill_merge launch: %s", hipGetErrorString(e));
+  }
   return LV_OK;
 }
 

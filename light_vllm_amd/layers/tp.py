@@ -30,7 +30,7 @@ def set_carrier(carrier) -> None:
 
 def all_reduce(t):
     """In-place sum over the TP group (reference: layers/linear.py:388-389). Decode-sized bf16
-    messages (up to 4 MiB) take the direct path over the peers' IPC-mapped buffers when a
+    messages (up to 8 MiB: every decode batch the graphs cover, 512 x 8192) take the direct path over the peers' IPC-mapped buffers when a
     communicator is installed (one kernel, hipGraph-capturable); everything else is RCCL."""
     direct = _comm.active()
     if direct is not None and direct.usable(t):

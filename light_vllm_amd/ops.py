@@ -73,12 +73,15 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                       cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
                       max_seqlen_q: int, max_seqlen_k: int, softmax_scale: float,
                       block_table: Optional[torch.Tensor] = None,
-                      out: Optional[torch.Tensor] = None, kernel: Optional[str] = None) -> torch.Tensor:
+                      out: Optional[torch.Tensor] = None, kernel: Optional[str] = None,
+                      num_splits: int = 0) -> torch.Tensor:
     """Varlen causal attention (bottom-right aligned mask), GQA, optional paged K/V.
 
     q: [total_q, Hq, D]. Packed mode: k/v [total_k, Hkv, D]. Paged mode (block_table given):
     k/v are the caches [num_blocks, block_size, Hkv, D] and block_table is int32 [B, max_blocks].
     kernel: a key of PREFILL_KERNELS to force one kernel (default: DEFAULT_KERNEL["prefill"]).
+    num_splits: KV splits per query tile (0 = library heuristic: only for few query rows against
+    a long context; 1 = one pass; n = n runs + a merge pass through the per-device workspace).
     """
     dev = _require_gpu(q, k, v, cu_seqlens_q, cu_seqlens_k)
     total_q, Hq, D = q.shape
@@ -111,13 +114,16 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     if total_q == 0 or B == 0:
         return out
     lib = _lib.load()
+    nsplit = num_splits if num_splits > 0 else lib.lv_prefill_num_splits(B, int(max_seqlen_q), int(max_seqlen_k), Hq)
+    ws_ptr, ws_bytes, keep = _workspace(dev, lib.lv_prefill_workspace_bytes(total_q, Hq, D, nsplit))
     with torch.cuda.device(dev):
         rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                  q.stride(0), k_stride0, v_stride0, out.stride(0),
                                  cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), B,
                                  int(max_seqlen_q), int(max_seqlen_k), bt_ptr, bt_stride, block_size,
-                                 Hq, Hkv, D, float(softmax_scale),
+                                 Hq, Hkv, D, float(softmax_scale), total_q, ws_ptr, ws_bytes, nsplit,
                                  PREFILL_KERNELS[kernel or DEFAULT_KERNEL["prefill"]], _stream_ptr(dev))
+    del keep
     _lib.check(rc, "lv_prefill_attn")
     return out
 

@@ -20,6 +20,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
+        "lv_prefill_num_splits", "lv_prefill_workspace_bytes",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
         "lv_comm_destroy"])
 
@@ -50,6 +51,16 @@ def test_host_only_entry_points():
     assert lib.lv_decode_num_splits(64, 8, 16, 256) == 4      # 64 sequences: cut in 4 for ~256 read streams
     assert lib.lv_decode_num_splits(256, 1, 16, 256) == 1     # 256 sequences are streams enough
     assert lib.lv_decode_num_splits(8, 1, 16, 256) == 32      # few units: one workgroup per CU
+    # prefill: no KV splits while the query tiles alone give every CU a workgroup or the context is short ...
+    assert lib.lv_prefill_num_splits(4, 4096, 4096, 32) == 1
+    assert lib.lv_prefill_num_splits(1, 100, 400, 8) == 1
+    # ... else about two workgroups per CU, runs of at least eight 64-key tiles, at most 32
+    assert lib.lv_prefill_num_splits(8, 100, 4196, 8) == 8       # 64 workgroups, 66 tiles
+    assert lib.lv_prefill_num_splits(8, 100, 4196, 32) == 2      # 256 workgroups
+    assert lib.lv_prefill_num_splits(1, 100, 32768, 8) == 32     # 8 workgroups, 512 tiles
+    assert lib.lv_prefill_num_splits(1, 40, 1064, 8) == 2        # 17 tiles: runs of >= 8
+    assert lib.lv_prefill_workspace_bytes(300, 8, 128, 4) == 300 * 8 * 4 * 130 * 4
+    assert lib.lv_prefill_workspace_bytes(300, 8, 128, 1) == 0
 
 
 def test_argument_validation_happens_before_any_launch():
@@ -75,10 +86,10 @@ def test_argument_validation_happens_before_any_launch():
     rc = lib.lv_store_kvcache(p16, p16, 512, 1024, p16, p16, p16, 1, 8, 128, 256, None)
     assert rc == -1
     # heads not divisible
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 8, None, 0, 1, 0, None)
     assert rc == -1
     # scale must be finite and positive (a zero scale would turn the pre-scaled prefill kernel's constants into NaN)
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 8, None, 0, 1, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()
     rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, float("nan"), None, 0, 1, None, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()

@@ -13,8 +13,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# elements: one 16-byte vector, a ragged count, [1, 4096] .. [256, 4096] activations, [256, 5120], the 4 MiB limit
-SIZES = [8, 8 * 37, 4096, 32 * 4096, 64 * 4096, 256 * 4096, 256 * 5120, 2 * 1024 * 1024]
+# elements: one 16-byte vector, a ragged count, [1, 4096] .. [256, 4096] activations, [256, 5120], the 8 MiB limit
+SIZES = [8, 8 * 37, 4096, 32 * 4096, 64 * 4096, 256 * 4096, 256 * 5120, 2 * 1024 * 1024, 4 * 1024 * 1024]
 
 
 def _free_port():

@@ -19,19 +19,19 @@ def kernel_config(request, monkeypatch):
     return request.param
 
 
-def _run(gpu, case):
+def _run(gpu, case, num_splits=0):
     from light_vllm_amd import ops
     d = to_dev(case, gpu)
     out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"],
-                                d["scale"], block_table=d["block_table"])
+                                d["scale"], block_table=d["block_table"], num_splits=num_splits)
     torch.cuda.synchronize()
     return out
 
 
-def _check(gpu, case):
+def _check(gpu, case, num_splits=0):
     ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"],
                       case["block_table"])
-    out = _run(gpu, case)
+    out = _run(gpu, case, num_splits)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err <= TOL, f"max-abs {err}"
     return out
@@ -138,3 +138,39 @@ def test_prefill_spiked_scores_long(gpu):
     case["k"][2000 + 40, 0] = (case["q"][2200, 5].float() * 5.0).to(torch.bfloat16)
     case["k"][2303, 0] = (case["q"][2303, 7].float() * 6.0).to(torch.bfloat16)
     _check(gpu, case)
+
+
+# ---- KV splits of the query tiles (few query rows against a long context). Forced counts run
+# ---- under every kernel hint of the fixture; the two long-prompt kernels hand over to the 8-wave one.
+@pytest.mark.parametrize("num_splits", [2, 5, 32])
+def test_prefill_split_kv_packed_ragged(gpu, num_splits):
+    """Ragged packed batch: tile counts below, at and above the split count, so some runs are empty."""
+    lens = [1, 63, 64, 65, 300, 1000, 2100]
+    _check(gpu, make_prefill_case(31, lens, lens, 16, 8), num_splits=num_splits)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1)])
+@pytest.mark.parametrize("num_splits", [0, 3, 8])
+def test_prefill_split_kv_prefix_cached(gpu, Hq, Hkv, num_splits):
+    """The shape the splits are for: a few new tokens per sequence on top of a long cached prefix,
+    read through the block table (BASELINE config 5's prefix-cache hits). 0 = the heuristic, which
+    splits here (2 or 3 query tiles x heads against 36-70 key tiles)."""
+    from light_vllm_amd import ops
+    lens_k = [2304 + 40, 4352 + 100, 1024 + 7]
+    cached = [2304, 4352, 1024]
+    lens_q = [k - c for k, c in zip(lens_k, cached)]
+    if num_splits == 0:
+        assert ops._lib.load().lv_prefill_num_splits(3, max(lens_q), max(lens_k), Hq) > 1
+    _check(gpu, make_prefill_case(32, lens_q, lens_k, Hq, Hkv, paged=True), num_splits=num_splits)
+
+
+def test_prefill_split_kv_spiked_and_bit_stable(gpu):
+    """A run that holds a score far above the others must dominate the merge; and the split path is
+    deterministic (two launches, same bits)."""
+    case = make_prefill_case(33, [200], [200 + 1792], 16, 8, paged=True)
+    bt = case["block_table"]
+    t = 1900
+    case["k"][int(bt[0, t // 256]), t % 256, 0] = (case["q"][150, 1].float() * 4.0).to(torch.bfloat16)
+    a = _check(gpu, case, num_splits=6)
+    b = _run(gpu, case, num_splits=6)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))

@@ -120,6 +120,30 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
 
 
+def prefix_case(B, new, cached, Hq, Hkv, nsplit):
+    """Prefix-cached prefill: `new` query tokens per sequence on top of `cached` tokens in the paged
+    cache (Lk = cached + new), nsplit KV runs per query tile (0 = library heuristic, 1 = one pass)."""
+    Lk = cached + new
+    bps = (Lk + BLOCK - 1) // BLOCK
+    nblk = B * bps
+    kc = torch.randn(nblk, BLOCK, Hkv, D, device=dev).to(torch.bfloat16)
+    vc = torch.randn(nblk, BLOCK, Hkv, D, device=dev).to(torch.bfloat16)
+    q = torch.randn(B * new, Hq, D, device=dev).to(torch.bfloat16)
+    bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
+    cu_q = torch.arange(0, (B + 1) * new, new, dtype=torch.int32, device=dev)
+    cu_k = torch.arange(0, (B + 1) * Lk, Lk, dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+
+    def fn():
+        ops.prefill_attention(q, kc, vc, cu_q, cu_k, new, Lk, D ** -0.5, block_table=bt, out=out, num_splits=nsplit)
+
+    t = timeit_graph(fn, iters=10, warmup=5)
+    flops = B * 4 * Hq * D * (new * Lk - new * (new - 1) // 2)
+    ns = nsplit or ops._lib.load().lv_prefill_num_splits(B, new, Lk, Hq)
+    return dict(kind="prefill_prefix", B=B, new=new, cached=cached, Hq=Hq, Hkv=Hkv, nsplit=ns, us=round(t * 1e6, 1),
+                TFLOPs=round(flops / t / 1e12, 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="decode")
@@ -163,6 +187,12 @@ def main():
         for lens, Hq, Hkv in (([2048] * 8, 4, 1), ([4096] * 4, 4, 1), ([1024] * 16, 4, 1), ([4096] * 2, 8, 2),
                               ([1024] * 16, 32, 8), ([4096] * 4, 32, 8)):
             rows.append(prefill_case(lens, Hq, Hkv))
+    if args.what == "prefill_prefix":    # few new tokens on a long cached prefix: one pass vs KV runs
+        for (B, new, cached, Hq, Hkv) in [(8, 100, 4096, 8, 1), (8, 100, 4096, 32, 8), (1, 100, 32000, 8, 1),
+                                          (4, 300, 1024, 8, 1), (2, 512, 8192, 32, 8), (1, 4096, 0, 4, 1),
+                                          (6, 300, 1024, 8, 1)]:
+            for ns in (1, 0, 2, 4, 8):
+                rows.append(prefix_case(B, new, cached, Hq, Hkv, ns))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_8b":         # the north-star shapes and their TP shards, uniform and ragged

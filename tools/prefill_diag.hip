@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
   p.cu_q = dcu; p.cu_k = dcu; p.block_table = nullptr; p.bt_stride = 0; p.block_size = 0;
   p.batch = B; p.max_seqlen_q = L; p.num_heads = Hq; p.num_kv_heads = Hkv;
   p.kernel_hint = hint;
+  p.nsplit = 1; p.ws_o = nullptr; p.ws_ml = nullptr; p.total_q = (int64_t)B * L;
   p.scale_log2e = 0.08838834764f * 1.4426950408889634f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> times;
