@@ -68,12 +68,35 @@ class DirectAllReduce:
             self._comm = None
 
 
-def create_for_group(device: torch.device, timeout_ms: int = 0, group=None) -> Optional[DirectAllReduce]:
+def _self_test(comm: DirectAllReduce) -> str:
+    """Known-answer sums through both algorithms on the freshly connected communicator: rank r
+    contributes (r + 1) * (i % 8) at element i, so every element of the result is the small integer
+    world * (world + 1) / 2 * (i % 8), exact in bf16. Returns "" or what went wrong. A peer mapping
+    that opened but does not carry data or flags between these GPUs shows up here (as a wrong sum
+    or as the kernel's bounded wait running out), before the model depends on it."""
+    world = comm.world_size
+    for algorithm, n in (("one_shot", 4096), ("two_shot", 64 * 4096), ("auto", 1024 * 1024), ("one_shot", 8)):
+        pattern = (torch.arange(n, device=comm.device) % 8).to(torch.float32)
+        x = (pattern * (comm.rank + 1)).to(torch.bfloat16)
+        comm.all_reduce(x, algorithm)
+        torch.cuda.synchronize(comm.device)
+        if comm.failed():
+            return f"{algorithm} of {n} elements: a peer did not arrive within the timeout"
+        want = (pattern * (world * (world + 1) // 2)).to(torch.bfloat16)
+        if not torch.equal(x, want):
+            bad = int((x != want).sum())
+            return f"{algorithm} of {n} elements: {bad} wrong sums"
+    return ""
+
+
+def create_for_group(device: torch.device, timeout_ms: int = 0, group=None,
+                     self_test: bool = True) -> Optional[DirectAllReduce]:
     """Collective over `group`: every rank builds its end, the handles travel through the group, every
-    rank maps its peers. Each local step is followed by an exchange of its outcome, so that a rank
-    on which a step fails (IPC can be unavailable, e.g. ranks in different containers) never leaves
-    the others waiting in a different collective: all ranks keep the communicator or all drop it
-    together and stay on torch.distributed. Returns None then."""
+    rank maps its peers, and (self_test) known-answer sums run through both algorithms. Each local
+    step is followed by an exchange of its outcome, so that a rank on which a step fails (IPC can be
+    unavailable, e.g. ranks in different containers) never leaves the others waiting in a different
+    collective: all ranks keep the communicator or all drop it together and stay on
+    torch.distributed. Returns None then."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
 
     def agree(ok: bool, payload):
@@ -110,6 +133,15 @@ def create_for_group(device: torch.device, timeout_ms: int = 0, group=None) -> O
     if not ok:
         return give_up(comm, reasons)
     dist.barrier(group=group)         # every rank has mapped every peer before the first use
+    if self_test:
+        try:
+            err = _self_test(comm)
+        except Exception as exc:      # noqa: BLE001
+            err = repr(exc)
+        ok, reasons = agree(not err, err)
+        if not ok:
+            dist.barrier(group=group)  # nobody unmaps while a peer's kernel may still read
+            return give_up(comm, reasons)
     return comm
 
 
