@@ -273,7 +273,9 @@ def time_all_reduce(fn, x, iters=50):
 def collectives_leg(dist, dev, n, direct):
     """Average time of the in-place bf16 sum all-reduce of the TP model at its decode-sized
     messages ([32, 4096] and [256, 4096]) on the direct IPC path and on RCCL, and at the
-    prefill-sized message ([16384, 4096], RCCL only); busbw = 2(n-1)/n * bytes / t."""
+    prefill-sized message ([16384, 4096], RCCL only); busbw = 2(n-1)/n * bytes / t.
+    A failure of the direct path on this rank is recorded per message and never skips a later
+    RCCL call: every rank issues the same torch.distributed collectives in the same order."""
     out = {}
     for name, rows in (("decode_256KiB", 32), ("decode_2MiB", 256), ("prefill_128MiB", 16384)):
         x = torch.ones(rows, 4096, dtype=torch.bfloat16, device=dev)
@@ -283,9 +285,15 @@ def collectives_leg(dist, dev, n, direct):
             rec["rccl_us"] = round(us, 1)
             rec["rccl_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
         if direct is not None and direct.usable(x):
-            us = time_all_reduce(direct.all_reduce, x)
-            rec["direct_us"] = round(us, 1)
-            rec["direct_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
+            try:
+                us = time_all_reduce(direct.all_reduce, x)
+                if direct.failed():
+                    raise RuntimeError("a peer did not arrive within the communicator's timeout")
+                rec["direct_us"] = round(us, 1)
+                rec["direct_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
+            except Exception as exc:   # noqa: BLE001 - recorded; the RCCL sequence below stays in step
+                rec["direct_error"] = repr(exc)[:200]
+                torch.cuda.synchronize()
         out[name] = rec
         del x
     return out
@@ -447,11 +455,36 @@ def main():
         from light_vllm_amd.layers import tp
         w, hidden = tp_step_setup(ops, dev, n, rank, c, layers, batch)
         use_graph = direct is not None or backend == "nccl"
-        elapsed, graphed, note = run_steps(lambda: w.step(after_layer=lambda: tp.all_reduce(hidden)),
-                                           args.steps, args.warmup, sync_all, use_graph)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cpu_or_dev = dev if backend == "nccl" else "cpu"
+
+        def timed_step():
+            """(max elapsed over ranks, graph used, note, failed on any rank). A rank whose direct
+            all-reduce gives up (bounded waits: every rank's kernels end) reports it instead of
+            leaving; the ranks then agree through torch.distributed."""
+            failed, el, graphed, note = 0.0, 0.0, False, None
+            try:
+                el, graphed, note = run_steps(lambda: w.step(after_layer=lambda: tp.all_reduce(hidden)),
+                                              args.steps, args.warmup, sync_all, use_graph)
+                if direct is not None and lvcomm.active() is not None and direct.failed():
+                    raise RuntimeError("direct all-reduce: a peer did not arrive within the timeout")
+            except Exception as exc:   # noqa: BLE001
+                failed, note = 1.0, f"rank {rank}: {exc!r}"[:300]
+                torch.cuda.synchronize()
+            t = torch.tensor([el, failed], dtype=torch.float64, device=cpu_or_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0].item()), graphed, note, bool(t[1].item() > 0)
+
+        elapsed, graphed, note, bad = timed_step()
+        direct_fell_back = False
+        if bad and direct is not None and backend == "nccl":
+            # the direct transport failed on some rank: time the same step on RCCL instead
+            lvcomm.install(None)
+            direct_fell_back = True
+            hidden.fill_(1.0)
+            elapsed, graphed, note2, bad = timed_step()
+            note = f"direct all-reduce failed ({note}); re-timed on RCCL" + (f"; {note2}" if note2 else "")
+        if bad:
+            raise SystemExit(f"bench: the timed step failed on some rank: {note}")
         value = n * w.step_bytes * args.steps / elapsed / 1e9
         kern = "decode_mfma_kernel<4>"
         roof = w.roofline(2, kern)
@@ -464,13 +497,14 @@ def main():
                                    f"{w.Hq}q/{w.Hkv}kv, D={D}, " + ("hipGraph replay" if graphed else "eager launches"),
                        "global_batch": batch, "context_len": c["ctx"], "parallelism": f"tp{n}",
                        "decode_splits": w.nsplit, "hipgraph": graphed, "rehearsal": bool(args.rehearse),
-                       "all_reduce": "direct (lv_comm over IPC-mapped peer buffers)" if direct is not None else backend,
+                       "all_reduce": "direct (lv_comm over IPC-mapped peer buffers)"
+                                     if direct is not None and not direct_fell_back else backend,
                        "all_reduce_bytes": msg},
             "rccl_ranks": dist.get_world_size(), "dist_backend": backend,
             "pct_hbm_peak": round(100.0 * roof["frac"], 2), "roofline": roof})
         if note:
             result["config"]["graph_note"] = note
-        if direct is not None and direct.failed():
+        if direct is not None and (direct_fell_back or direct.failed()):
             result["comm_failed"] = True
         del hidden
         w.free()
@@ -500,7 +534,7 @@ def main():
             result["config4_tp1"] = {"error": repr(exc)[:300]}
     if n > 1 and not args.no_aux:
         try:
-            result["collectives"] = collectives_leg(dist, dev, n, direct)
+            result["collectives"] = collectives_leg(dist, dev, n, None if direct_fell_back else direct)
         except Exception as exc:
             result["collectives"] = {"error": repr(exc)[:300]}
     torch.cuda.empty_cache()
