@@ -66,6 +66,9 @@ def store_bytes(N, Hkv):
     return 2 * (N * Hkv * D * 2 * 2) + 4 * N
 
 
+SETTLE_S = 1.0   # idle time between a leg's set-up and its first timed launch
+
+
 class DecodeWorkload:
     """The per-layer tensors of one decode step on this rank: one KV tensor for all layers, as
     ModelRunner.allocate_kv_cache lays it out, so no layer's cache is served from the Infinity Cache
@@ -94,6 +97,12 @@ class DecodeWorkload:
         ops.reserve_decode_workspace(dev, ops.decode_workspace_bytes(B, Hq, D, self.nsplit))
         self.decode_bytes = decode_bytes(B, ctx, Hq, Hkv)
         self.step_bytes = layers * (self.decode_bytes + store_bytes(B, Hkv))
+        # For up to ~0.8 s after a large hipFree or fill (the previous leg's caches, this leg's random
+        # numbers) the same launch on the same buffers runs 3-5 % slower, then returns to the time it
+        # holds for thousands of back-to-back launches (tools/decode_state_probe.py). Every leg
+        # starts from that settled state, not from the tail of its own set-up.
+        torch.cuda.synchronize()
+        time.sleep(SETTLE_S)
 
     def step(self, events=None, after_layer=None):
         ops, kv = self.ops, self.kv
@@ -419,7 +428,8 @@ def main():
 
     result = {"metric": "paged-decode attn HBM GB/s", "unit": "GB/s", "n_gpus": n, "steps": args.steps,
               "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "bf16",
-              "data": "synthetic (seeded N(0,1) bf16 q/K/V, random physical block permutation)"}
+              "data": "synthetic (seeded N(0,1) bf16 q/K/V, random physical block permutation)",
+              "settle_s": SETTLE_S}
 
     if n == 1:
         c = C2

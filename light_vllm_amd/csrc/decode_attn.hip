@@ -25,6 +25,13 @@ namespace lv {
 // tokens starting at a multiple of 4*U never straddles two blocks).
 constexpr int kSplitUnit = 64;
 
+// Diagnostic builds only (tools/decode_abl.sh): pieces of the vector-ALU kernel's arithmetic
+// compiled out, results then wrong by design. 1 = dot products, 2 = 16-lane reductions,
+// 4 = exponentials, 8 = p.V accumulation. The library is built with 0.
+#ifndef LV_DECODE_ABL
+#define LV_DECODE_ABL 0
+#endif
+
 template <bool NT>
 __device__ __forceinline__ u32x4 load16(const uint16_t* p) {
   if constexpr (NT) {
@@ -153,10 +160,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
 #pragma unroll
         for (int h = 0; h < G; ++h) {
           float d = 0.f;
-          d = dot2_bf16(kb[u][0], qv[h][0], d);
-          d = dot2_bf16(kb[u][1], qv[h][1], d);
-          d = dot2_bf16(kb[u][2], qv[h][2], d);
-          d = dot2_bf16(kb[u][3], qv[h][3], d);
+          if constexpr ((LV_DECODE_ABL & 1) == 0) {
+            d = dot2_bf16(kb[u][0], qv[h][0], d);
+            d = dot2_bf16(kb[u][1], qv[h][1], d);
+            d = dot2_bf16(kb[u][2], qv[h][2], d);
+            d = dot2_bf16(kb[u][3], qv[h][3], d);
+          } else {
+            d = bf16_lo((kb[u][0] ^ kb[u][1]) + (kb[u][2] ^ kb[u][3]) + qv[h][0]);
+          }
           s[u][h] = d;
         }
       }
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
         const bool ok = (4 * u + g) < valid;
 #pragma unroll
         for (int h = 0; h < G; ++h) {
-          const float r = row16_allreduce_sum(s[u][h]) * p.scale_log2e;
+          const float r = ((LV_DECODE_ABL & 2) ? s[u][h] : row16_allreduce_sum(s[u][h])) * p.scale_log2e;
           s[u][h] = ok ? r : -INFINITY;
         }
       }
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
         float psum = 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const float pe = fast_exp2(s[u][h] - m_use);
+          const float pe = (LV_DECODE_ABL & 4) ? s[u][h] - m_use : fast_exp2(s[u][h] - m_use);
           s[u][h] = pe;
           psum += pe;
         }
@@ -199,16 +210,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
       // ---- acc += p * V
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float vf[8];
+        if constexpr ((LV_DECODE_ABL & 8) == 0) {
+          float vf[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vf[2 * j] = bf16_lo(vb[u][j]);
-          vf[2 * j + 1] = bf16_hi(vb[u][j]);
-        }
+          for (int j = 0; j < 4; ++j) {
+            vf[2 * j] = bf16_lo(vb[u][j]);
+            vf[2 * j + 1] = bf16_hi(vb[u][j]);
+          }
 #pragma unroll
-        for (int h = 0; h < G; ++h) {
+          for (int h = 0; h < G; ++h) {
 #pragma unroll
-          for (int d = 0; d < 8; ++d) acc[h][d] = fmaf(s[u][h], vf[d], acc[h][d]);
+            for (int d = 0; d < 8; ++d) acc[h][d] = fmaf(s[u][h], vf[d], acc[h][d]);
+          }
+        } else {
+          const float vx = bf16_lo((vb[u][0] ^ vb[u][1]) + (vb[u][2] ^ vb[u][3]));
+#pragma unroll
+          for (int h = 0; h < G; ++h) acc[h][u & 7] = fmaf(s[u][h], vx, acc[h][u & 7]);
         }
       }
       if (has_next) {

@@ -50,13 +50,17 @@ def timeit_graph(fn, iters=20, warmup=3, replays=5):
     return e0.elapsed_time(e1) / (iters * replays) * 1e-3
 
 
-def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False, graph=False):
+def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False, graph=False, data="normal"):
     bps = (ctx + BLOCK - 1) // BLOCK
     nblk = B * bps
     # several distinct caches so the working set exceeds the 256 MiB Infinity Cache
     per_layer = 2 * nblk * BLOCK * Hkv * D * 2
     layers = max(layers, min(64, (1 << 30) // max(per_layer, 1) + 1))
-    kv = torch.empty(layers, 2, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev).normal_()
+    kv = torch.empty(layers, 2, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev)
+    if data == "normal":
+        kv.normal_()
+    else:                       # "zeros": the same bytes moved, no switching in the arithmetic
+        kv.zero_()
     q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
     bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
     if ragged:
@@ -81,7 +85,8 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
     nb = int(((lens + BLOCK - 1) // BLOCK).sum())
     bytes_ = tot * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nb
     ns = nsplit or ops.decode_num_splits(B, Hkv, bps, BLOCK)
-    return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, ordered=ordered, us=round(t * 1e6, 1),
+    return dict(kind="decode", B=B, ctx=ctx, Hq=Hq, Hkv=Hkv, nsplit=ns, ragged=ragged, ordered=ordered, data=data,
+                kernel=ops.DEFAULT_KERNEL["decode"], us=round(t * 1e6, 1),
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
 
@@ -195,6 +200,25 @@ def main():
                 rows.append(prefix_case(B, new, cached, Hq, Hkv, ns))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
+    if args.what == "decode_c2":         # the bench launch: both kernels, random and all-zero caches, eager and replayed
+        for data in ("normal", "zeros"):
+            for graph in (False, True):
+                rows.append(decode_case(256, 1024, 16, 8, data=data, graph=graph))
+                rows.append(decode_case(256, 1024, 32, 8, data=data, graph=graph))
+    if args.what == "decode_drift":      # the same two launches again and again: does the chip's state drift?
+        import time as _time
+        t_start = _time.perf_counter()
+        for rep in range(12):
+            for (Hq, Hkv) in ((16, 8), (32, 8)):
+                r = decode_case(256, 1024, Hq, Hkv, layers=4, graph=True)
+                r["t_s"] = round(_time.perf_counter() - t_start, 1)
+                rows.append(r)
+    if args.what == "decode_footprint":  # the same launch rotating over 4, 12 and 36 layer caches (8, 24, 72 GiB)
+        for layers in (4, 12, 36, 4):
+            for (Hq, Hkv) in ((16, 8), (32, 8)):
+                r = decode_case(256, 1024, Hq, Hkv, layers=layers, graph=True)
+                r["layers"] = layers
+                rows.append(r)
     if args.what == "decode_8b":         # the north-star shapes and their TP shards, uniform and ragged
         for (Hq, Hkv) in [(32, 8), (16, 4), (8, 2), (4, 1), (64, 8), (8, 1)]:
             rows.append(decode_case(256, 1024, Hq, Hkv, graph=True))
