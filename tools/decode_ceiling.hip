@@ -13,12 +13,20 @@ constexpr int Hkv = 8, CTX = 1024, B = 256, BS = 256, U = 8, TOK = 4 * U;
 
 // LDS_KB > 0 reserves that much LDS per workgroup, which caps the workgroups a CU holds at once
 // (160 KiB per CU: 56 -> 2, 48 -> 3, 36 -> 4, 0 -> all 8 of this launch).
-template <bool PIPE, bool PRO, bool EPI, int LDS_KB = 0>
+// ORD: 0 = sequence index is the launch position; 1 = positions walk `order` (longest first);
+// 2 = as 1, in groups of 32 positions x all kv heads (the real kernel's order for ragged batches).
+template <bool PIPE, bool PRO, bool EPI, int LDS_KB = 0, int ORD = 0>
 __global__ __launch_bounds__(256) void rd(const char* __restrict__ k, const char* __restrict__ v,
                                           const int* __restrict__ ctx_lens, const int* __restrict__ bt,
-                                          unsigned* __restrict__ out) {
+                                          unsigned* __restrict__ out, const int* __restrict__ order = nullptr) {
   const int bid = blockIdx.x;
-  const int seq = bid % B, kvh = bid / B;
+  int seq = bid % B, kvh = bid / B;
+  if constexpr (ORD == 1) seq = order[seq];
+  if constexpr (ORD == 2) {
+    const int grp = bid / (32 * Hkv), rem = bid % (32 * Hkv);
+    seq = order[grp * 32 + rem % 32];
+    kvh = rem / 32;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t row = (size_t)Hkv * 256;
   const int ctx = PRO ? ctx_lens[seq] : CTX;
@@ -89,7 +97,22 @@ __global__ __launch_bounds__(256) void rd(const char* __restrict__ k, const char
   }
 }
 
-struct Bufs { char *k[2], *v[2]; int *ctx, *bt; unsigned* out; };
+struct Bufs { char *k[2], *v[2]; int *ctx, *bt, *ctx_ragged, *order; unsigned* out; double ragged_tokens; };
+
+template <int ORD>
+static void run_ragged(const Bufs& s, const char* name) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int it = 0; it < 6; ++it)
+    hipLaunchKernelGGL((rd<true, true, true, 0, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
+  const int n = 30;
+  hipEventRecord(a);
+  for (int it = 0; it < n; ++it)
+    hipLaunchKernelGGL((rd<true, true, true, 0, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  const double us = ms * 1e3 / n, bytes = 2.0 * s.ragged_tokens * Hkv * 256;
+  printf("RESULT {\"variant\": \"%s\", \"us\": %.1f, \"GBs\": %.0f, \"frac_8TBs\": %.3f}\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 8000.0);
+}
 
 template <bool PIPE, bool PRO, bool EPI, int LDS_KB = 0>
 static void run(const Bufs& s, const char* name) {
@@ -120,6 +143,14 @@ int main() {
   for (int i = 0; i < B; ++i) hctx[i] = CTX;
   // block permutation: a fixed odd multiplier modulo the power-of-two block count (a bijection)
   for (int i = 0; i < nblk; ++i) hbt[i] = (int)(((unsigned)i * 617u + 311u) % (unsigned)nblk);
+  // ragged batch: lengths 32 .. 1024 in steps of 32 (a fixed linear congruential draw), and the longest-first order
+  int hrag[B], hord[B];
+  unsigned lcg = 12345u; s.ragged_tokens = 0;
+  for (int i = 0; i < B; ++i) { lcg = lcg * 1664525u + 1013904223u; hrag[i] = 32 * (1 + (lcg >> 16) % 32); s.ragged_tokens += hrag[i]; hord[i] = i; }
+  for (int i = 0; i < B; ++i) for (int j = i + 1; j < B; ++j) if (hrag[hord[j]] > hrag[hord[i]]) { int t = hord[i]; hord[i] = hord[j]; hord[j] = t; }
+  hipMalloc(&s.ctx_ragged, B * 4); hipMalloc(&s.order, B * 4);
+  hipMemcpy(s.ctx_ragged, hrag, sizeof(hrag), hipMemcpyHostToDevice);
+  hipMemcpy(s.order, hord, sizeof(hord), hipMemcpyHostToDevice);
   hipMemcpy(s.ctx, hctx, sizeof(hctx), hipMemcpyHostToDevice);
   hipMemcpy(s.bt, hbt, sizeof(hbt), hipMemcpyHostToDevice);
   for (int rep = 0; rep < 2; ++rep) {
@@ -131,6 +162,9 @@ int main() {
     run<true, true, true, 36>(s, "pipelined+prologue+epilogue, 4 workgroups per CU");
     run<true, true, true, 48>(s, "pipelined+prologue+epilogue, 3 workgroups per CU");
     run<true, true, true, 56>(s, "pipelined+prologue+epilogue, 2 workgroups per CU");
+    run_ragged<0>(s, "ragged 32..1024, natural order");
+    run_ragged<1>(s, "ragged 32..1024, longest first");
+    run_ragged<2>(s, "ragged 32..1024, longest first in groups of 32 x all heads");
   }
   return 0;
 }
