@@ -72,11 +72,13 @@ def test_fuzz_prefill(gpu, monkeypatch, seed):
         lens_k = list(lens_q)
     cfg = ["auto", "0", "1", "2", "4"][int(torch.randint(0, 5, (), generator=g))]
     monkeypatch.setitem(ops.DEFAULT_KERNEL, "prefill", {"auto": "auto", "0": "w4", "1": "w8", "2": "pp", "4": "w64"}[cfg])
+    # KV runs: the library's choice, none, or a forced count (also more runs than some sequences have key tiles)
+    ns = [0, 0, 1, 2, 3, 5, 8][int(torch.randint(0, 7, (), generator=g))]
     case = make_prefill_case(4000 + seed, lens_q, lens_k, Hq, Hkv, block_size=block, paged=paged)
     d = to_dev(case, gpu)
     out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
-                                block_table=d["block_table"])
+                                block_table=d["block_table"], num_splits=ns)
     torch.cuda.synchronize()
     ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"], case["block_table"])
     err = (out.float().cpu() - ref).abs().max().item()
-    assert err <= TOL, f"seed {seed}: Hq/Hkv {Hq}/{Hkv} cfg {cfg} paged {paged} block {block} lens {lens_q}/{lens_k}: max-abs {err}"
+    assert err <= TOL, f"seed {seed}: Hq/Hkv {Hq}/{Hkv} cfg {cfg} runs {ns} paged {paged} block {block} lens {lens_q}/{lens_k}: max-abs {err}"
