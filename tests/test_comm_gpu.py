@@ -14,6 +14,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # elements: one 16-byte vector, a ragged count, [1, 4096] .. [256, 4096] activations, [256, 5120], the 8 MiB limit
+ROUNDS = int(os.environ.get("LV_COMM_ROUNDS", "3"))      # more rounds for a soak run
+GRAPH_REPLAYS = int(os.environ.get("LV_COMM_REPLAYS", "3"))
 SIZES = [8, 8 * 37, 4096, 32 * 4096, 64 * 4096, 256 * 4096, 256 * 5120, 2 * 1024 * 1024, 4 * 1024 * 1024]
 
 
@@ -36,7 +38,7 @@ def _expected(parts):
     return acc.to(torch.bfloat16)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, rounds):
     import torch.distributed as dist
     from light_vllm_amd import comm as lvcomm
     dev = torch.device("cuda:0")
@@ -47,7 +49,9 @@ def _worker(rank, world, port, out_dir):
     assert c is not None, "IPC communicator could not be built"
     # eager, sizes up and down, three rounds: consecutive calls alternate the staging parity
     salt = 0
-    for rnd in range(3):
+    for rnd in range(rounds):
+        if rank == 0 and rounds > 3:
+            print(f"world {world}: round {rnd} of {rounds}, {len(res['bad'])} bad so far", flush=True)   # a soak run stays audible
         for n in SIZES + SIZES[::-1]:
             salt += 1
             parts = _inputs(world, n, salt)
@@ -75,7 +79,7 @@ def _worker(rank, world, port, out_dir):
     with torch.cuda.graph(graph):
         for b, algo in zip(bufs, ("one_shot", "two_shot", "two_shot")):
             c.all_reduce(b, algo)
-    for rep in range(3):
+    for rep in range(GRAPH_REPLAYS):
         all_parts = [_inputs(world, b.numel(), 9000 + 10 * rep + i) for i, b in enumerate(bufs)]
         for b, parts in zip(bufs, all_parts):
             b.copy_(parts[rank])
@@ -111,23 +115,24 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_direct_all_reduce_shared_gpu(gpu, tmp_path, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    rounds = ROUNDS if world < 8 or ROUNDS > 3 else 1     # eight ranks: one round keeps the default suite short
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), rounds)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(200)
+        p.join(200 + 10 * rounds)
         if p.is_alive():
             p.kill()
         assert p.exitcode == 0
     for r in range(world):
         res = json.load(open(os.path.join(str(tmp_path), f"comm_{r}.json")))
         assert not res["bad"], f"rank {r}: {res['bad'][:5]}"
-        assert res["calls"] == 3 * 2 * len(SIZES)
+        assert res["calls"] == rounds * 2 * len(SIZES)
         assert res["failed_after_use"] is False
         if r == 0:
             print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms")
