@@ -125,9 +125,9 @@ def _worker_lagcopy(rank, world, port, event, out_path):
         json.dump([list(s.completion_token_ids) for s in seqs], f)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_tp_free_running_tokens_identical(gpu, tmp_path, world):
-    """TP = 2 / 4 (per-rank 8q/4kv and 4q/2kv heads, hipGraph decode with 57 direct all-reduces per
+    """TP = 2 / 4 / 8 (per-rank 8q/4kv, 4q/2kv and 2q/1kv heads, hipGraph decode with 57 direct all-reduces per
     forward) changes the summation order of every all-reduce, yet the lag-copy fixture's margins
     (more than 140 bf16 steps at every step) make the greedy tokens independent of it: the first 64
     generated tokens of each sequence must equal the reference stack's TP = 1 run exactly."""
