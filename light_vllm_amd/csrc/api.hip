@@ -68,12 +68,19 @@ constexpr int kMaxPrefillSplits = 32;
 // tools/kbench.py --what prefill_prefix (forced 1/2/4/8 runs on seven shapes): 8 x 100 new tokens
 // on 4096 cached, 8q/1kv: 107 -> 39 us; 1 x 100 on 32000: 760 -> 44 us; 256 workgroups (8 x 100 on
 // 4096, 32q/8kv): 109 -> 95 us with 2 runs, slower from 8; 144 workgroups of 21 tiles: no gain.
+// Whole prompts (no cached prefix; --what prefill_split_full) gain the same way up to 128
+// workgroups (1 x 4096, 4q/1kv: 98 -> 47 us; 2 x 4096: 100 -> 64 us) but at 256 workgroups two
+// runs pay only on long prompts (1 x 16384, 4q/1kv: 381 -> 286 us; 4 x 4096, 4q/1kv: 104 -> 125 us,
+// where the unsplit launch also keeps the faster phase-locked kernel), so between 128 and 256
+// workgroups a launch that is not prefix-dominated splits only from 8192 keys.
 static int prefill_heuristic_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads) {
   if (batch <= 0 || max_seqlen_q <= 0 || max_seqlen_k <= 0 || num_heads <= 0) return 1;
   const int bm = max_seqlen_q <= 1024 ? 128 : 256;
   const int64_t wgs = static_cast<int64_t>((max_seqlen_q + bm - 1) / bm) * num_heads * batch;
   const int ktiles = (max_seqlen_k + 63) / 64;
   if (wgs > 256) return 1;
+  const bool prefix_dominated = max_seqlen_k >= 4 * static_cast<int64_t>(max_seqlen_q);
+  if (wgs > 128 && !prefix_dominated && ktiles < 128) return 1;
   int64_t n = (512 + wgs - 1) / wgs;
   if (n > ktiles / 8) n = ktiles / 8;
   if (n > kMaxPrefillSplits) n = kMaxPrefillSplits;

@@ -59,6 +59,11 @@ def test_host_only_entry_points():
     assert lib.lv_prefill_num_splits(8, 100, 4196, 32) == 2      # 256 workgroups
     assert lib.lv_prefill_num_splits(1, 100, 32768, 8) == 32     # 8 workgroups, 512 tiles
     assert lib.lv_prefill_num_splits(1, 40, 1064, 8) == 2        # 17 tiles: runs of >= 8
+    # whole prompts: up to 128 workgroups as above; 129..256 only from 8192 keys
+    assert lib.lv_prefill_num_splits(1, 4096, 4096, 4) == 8      # 64 workgroups
+    assert lib.lv_prefill_num_splits(2, 4096, 4096, 4) == 4      # 128 workgroups
+    assert lib.lv_prefill_num_splits(4, 4096, 4096, 4) == 1      # 256 workgroups, 64 tiles
+    assert lib.lv_prefill_num_splits(1, 16384, 16384, 4) == 2    # 256 workgroups, 256 tiles
     assert lib.lv_prefill_workspace_bytes(300, 8, 128, 4) == 300 * 8 * 4 * 130 * 4
     assert lib.lv_prefill_workspace_bytes(300, 8, 128, 1) == 0
 

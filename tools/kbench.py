@@ -90,7 +90,7 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
 
-def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
+def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=None, num_splits=0):
     total = sum(lens)
 
     def draw(h):
@@ -104,7 +104,7 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
     out = torch.empty_like(q)
 
     def fn():
-        ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out)
+        ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out, kernel=kernel, num_splits=num_splits)
 
     # matrix-bound kernels run ~19 % slower for the first ~10 ms after an idle GPU (clock ramp):
     # at least 20 untimed launches and 25 ms of them first, so that the timed ones see the clocks a
@@ -122,6 +122,7 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50):
     t = timeit(fn, iters=iters, warmup=2)
     flops = sum(4 * Hq * D * (L * L - L * (L - 1) // 2) for L in lens)
     return dict(kind="prefill", data=data, iters=iters, lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
+                kernel=kernel or ops.DEFAULT_KERNEL["prefill"], runs=num_splits,
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
 
 
@@ -188,6 +189,19 @@ def main():
         for lens, Hq, Hkv in (([512] * 32, 32, 8), ([1024] * 16, 32, 8), ([1536] * 10, 32, 8), ([2048] * 8, 32, 8),
                               ([4096] * 4, 32, 8), ([1024] * 16, 16, 8), ([2048] * 8, 4, 1)):
             rows.append(prefill_case(lens, Hq, Hkv))
+    if args.what == "prefill_tp8":       # one rank's share of a 4 x 4096 prefill at TP = 8: kernels x KV runs
+        ops.reserve_decode_workspace(dev, 1 << 30)
+        for Hq, Hkv in ((8, 1), (4, 1)):
+            for kernel in ("pp", "w8", "w64", "w4"):
+                rows.append(prefill_case([4096] * 4, Hq, Hkv, kernel=kernel, num_splits=1))
+            for ns in (0, 2, 4):
+                rows.append(prefill_case([4096] * 4, Hq, Hkv, kernel="w8", num_splits=ns))
+    if args.what == "prefill_split_full":  # whole prompts (no cached prefix) on small grids: one pass vs forced KV runs
+        ops.reserve_decode_workspace(dev, 1 << 30)
+        for B, L, Hq, Hkv in ((1, 4096, 4, 1), (2, 4096, 4, 1), (4, 4096, 4, 1), (1, 4096, 8, 1), (2, 4096, 8, 1),
+                              (1, 8192, 4, 1), (1, 16384, 4, 1), (1, 2048, 4, 1), (2, 2048, 8, 1), (1, 4096, 32, 8)):
+            for ns in (1, 2, 4, 8):
+                rows.append(prefill_case([L] * B, Hq, Hkv, num_splits=ns, iters=30))
     if args.what == "prefill_small":     # grids that fit the chip at once (TP = 8 shapes)
         for lens, Hq, Hkv in (([2048] * 8, 4, 1), ([4096] * 4, 4, 1), ([1024] * 16, 4, 1), ([4096] * 2, 8, 2),
                               ([1024] * 16, 32, 8), ([4096] * 4, 32, 8)):

@@ -1,7 +1,7 @@
 // Diagnostic harness (not shipped): builds the prefill kernel with s_memtime stamps and prints the
 // share of wave time spent in each loop segment. Build and run:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLV_STAMPS -Iinclude -Ilight_vllm_amd/csrc \
-//         tools/prefill_diag.hip -o tools/prefill_diag && tools/prefill_diag [seqlen [kernel_hint]]
+//         tools/prefill_diag.hip -o tools/prefill_diag && tools/prefill_diag [seqlen [kernel_hint [heads kv_heads]]]
 // kernel_hint: an LV_PREFILL_KERNEL_* value (0 = the library's choice, 3 = phase-locked, 5 = 64 rows per wave).
 #include <stdarg.h>
 #include <stdio.h>
@@ -28,7 +28,8 @@ static uint16_t rnd_bf16(uint64_t& s) {
 }
 
 int main(int argc, char** argv) {
-  const int B = 4, L = argc > 1 ? atoi(argv[1]) : 4096, Hq = 32, Hkv = 8, D = 128;
+  const int B = 4, L = argc > 1 ? atoi(argv[1]) : 4096, D = 128;
+  const int Hq = argc > 3 ? atoi(argv[3]) : 32, Hkv = argc > 4 ? atoi(argv[4]) : 8;
   const int hint = argc > 2 ? atoi(argv[2]) : LV_PREFILL_KERNEL_AUTO;
   const size_t nq = (size_t)B * L * Hq * D, nk = (size_t)B * L * Hkv * D;
   std::vector<uint16_t> hq(nq), hk(nk), hv(nk);
