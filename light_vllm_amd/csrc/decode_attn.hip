@@ -537,36 +537,43 @@ __global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams 
   }
 }
 
-// Combine the nsplit partial results of one (sequence, query head). 256 lanes = 8 groups of 32;
-// a lane owns 4 output dims (one 16-byte load per split) and its group walks splits g, g+8, ...,
-// so many independent loads are in flight; groups are merged through LDS.
+// Combine the nsplit partial results of one (sequence, query head). DS workgroups share one
+// (sequence, head), each merging 128 / DS of its output dims. 256 lanes = groups of 32 / DS lanes;
+// a lane owns 4 output dims (one 16-byte load per split) and its group walks splits g, g + NG, ...,
+// so many independent loads are in flight; groups are merged through LDS. DS = 4 is for launches
+// with few (sequence, head) pairs and many splits: four times the workgroups, each group's splits
+// in one round of loads.
+template <int DS>
 __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ ws_o,
                                                            const float* __restrict__ ws_ml,
                                                            uint16_t* __restrict__ o,
                                                            int64_t o_stride0, int num_heads,
                                                            int nsplit) {
-  __shared__ float sm_max[8];
-  __shared__ float sm_part[8][kHeadDim + 4];
-  const int bh = blockIdx.x;
+  constexpr int LPG = 32 / DS;          // lanes per group
+  constexpr int NG = 256 / LPG;         // groups
+  constexpr int DIMS = kHeadDim / DS;   // output dims of this workgroup
+  __shared__ float sm_max[4];
+  __shared__ float sm_part[NG][DIMS + 4];
+  const int bh = blockIdx.x / DS;
+  const int dim0 = (blockIdx.x % DS) * DIMS;
   const int b = bh / num_heads;
   const int hq = bh % num_heads;
   const int tid = threadIdx.x;
-  const int grp = tid >> 5;
-  const int ln = tid & 31;
+  const int grp = tid / LPG;
+  const int ln = tid % LPG;
   const int64_t base = static_cast<int64_t>(bh) * nsplit;
 
   // The first kPre partials of this group are requested before the maximum is known: the two
-  // load latencies (statistics, partial outputs) then overlap instead of following each other
-  // (one long sequence cut in 256: 4.9 -> see the design notes for the measured effect).
-  constexpr int kPre = 16;
+  // load latencies (statistics, partial outputs) then overlap instead of following each other.
+  constexpr int kPre = 16 / DS < 8 ? 8 : 16 / DS;
   float4 pv[kPre];
   float2 pml[kPre];
 #pragma unroll
   for (int j = 0; j < kPre; ++j) {
-    const int s = grp + 8 * j;
+    const int s = grp + NG * j;
     if (s < nsplit) {
       pml[j] = *reinterpret_cast<const float2*>(ws_ml + (base + s) * 2);
-      pv[j] = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + 4 * ln);
+      pv[j] = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + dim0 + 4 * ln);
     }
   }
 
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   float L = 0.f;
 #pragma unroll
   for (int j = 0; j < kPre; ++j) {
-    if (grp + 8 * j < nsplit) {
+    if (grp + NG * j < nsplit) {
       const float sc = fast_exp2(pml[j].x - Mu);
       acc.x += sc * pv[j].x;
       acc.y += sc * pv[j].y;
@@ -593,12 +600,11 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
       L += sc * pml[j].y;
     }
   }
-  // the rest, 16 splits per trip: the loop is a chain of load latencies (about 0.6 us per batch of
-  // loads in flight); up to 128 splits never get here, 256 take one trip
-#pragma unroll 16
-  for (int s = grp + 8 * kPre; s < nsplit; s += 8) {
+  // the rest: a chain of load latencies (about 0.6 us per batch of loads in flight)
+#pragma unroll 8
+  for (int s = grp + NG * kPre; s < nsplit; s += NG) {
     const float2 ml = *reinterpret_cast<const float2*>(ws_ml + (base + s) * 2);
-    const float4 v = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + 4 * ln);
+    const float4 v = *reinterpret_cast<const float4*>(ws_o + (base + s) * kHeadDim + dim0 + 4 * ln);
     const float sc = fast_exp2(ml.x - Mu);
     acc.x += sc * v.x;
     acc.y += sc * v.y;
@@ -607,17 +613,17 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
     L += sc * ml.y;
   }
   *reinterpret_cast<float4*>(&sm_part[grp][4 * ln]) = acc;
-  if (ln == 0) sm_part[grp][kHeadDim] = L;
+  if (ln == 0) sm_part[grp][DIMS] = L;
   __syncthreads();
-  if (tid < kHeadDim) {
+  if (tid < DIMS) {
     float val = 0.f, Lt = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < NG; ++g) {
       val += sm_part[g][tid];
-      Lt += sm_part[g][kHeadDim];
+      Lt += sm_part[g][DIMS];
     }
     const float r = Lt > 0.f ? val / Lt : 0.f;
-    o[static_cast<int64_t>(b) * o_stride0 + hq * kHeadDim + tid] = f32_to_bf16_bits(r);
+    o[static_cast<int64_t>(b) * o_stride0 + hq * kHeadDim + dim0 + tid] = f32_to_bf16_bits(r);
   }
 }
 
@@ -656,9 +662,16 @@ int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_attn launch: %s", hipGetErrorString(e));
   if (p.nsplit > 1) {
-    hipLaunchKernelGGL(decode_merge_kernel, dim3(static_cast<unsigned>(p.batch) * p.num_heads),
-                       dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads,
-                       p.nsplit);
+    const unsigned pairs = static_cast<unsigned>(p.batch) * p.num_heads;
+    // Few (sequence, head) pairs cut into many splits (one long sequence on a TP shard): four
+    // workgroups per pair. 1 x 32768 tokens, 4q/1kv, 256 splits: 11.8 -> 10.0 us for the launch pair
+    // under graph replay; eight per pair measured 10.2; below 128 splits nothing moves either way.
+    if (pairs <= 64 && p.nsplit >= 64)
+      hipLaunchKernelGGL(decode_merge_kernel<4>, dim3(pairs * 4), dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o,
+                         p.o_stride0, p.num_heads, p.nsplit);
+    else
+      hipLaunchKernelGGL(decode_merge_kernel<1>, dim3(pairs), dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o,
+                         p.o_stride0, p.num_heads, p.nsplit);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_merge launch: %s", hipGetErrorString(e));
   }
