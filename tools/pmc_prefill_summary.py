@@ -1,6 +1,6 @@
 """Summarises the counter passes of tools/pmc_prefill.sh for one prefill kernel into
 profiles/<tag>_prefill_pmc_<kernel>.json (+ one merged CSV of per-dispatch means), with the derived
-figures quoted in the design notes: matrix-pipe busy fraction, LDS instructions per (wave, key
+figures this repository quotes for the prefill kernels: matrix-pipe busy fraction, LDS instructions per (wave, key
 tile), LDS bank conflicts, wait fractions, L2 hit rate.
 
     python tools/pmc_prefill_summary.py gpurun_out/pmc_pp r02
