@@ -99,15 +99,15 @@ __global__ __launch_bounds__(256) void rd(const char* __restrict__ k, const char
 
 struct Bufs { char *k[2], *v[2]; int *ctx, *bt, *ctx_ragged, *order; unsigned* out; double ragged_tokens; };
 
-template <int ORD>
+template <int ORD, int LDS_KB = 0>
 static void run_ragged(const Bufs& s, const char* name) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int it = 0; it < 6; ++it)
-    hipLaunchKernelGGL((rd<true, true, true, 0, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
+    hipLaunchKernelGGL((rd<true, true, true, LDS_KB, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
   const int n = 30;
   hipEventRecord(a);
   for (int it = 0; it < n; ++it)
-    hipLaunchKernelGGL((rd<true, true, true, 0, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
+    hipLaunchKernelGGL((rd<true, true, true, LDS_KB, ORD>), dim3(B * Hkv), dim3(256), 0, 0, s.k[it & 1], s.v[it & 1], s.ctx_ragged, s.bt, s.out, s.order);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   const double us = ms * 1e3 / n, bytes = 2.0 * s.ragged_tokens * Hkv * 256;
@@ -165,6 +165,9 @@ int main() {
     run_ragged<0>(s, "ragged 32..1024, natural order");
     run_ragged<1>(s, "ragged 32..1024, longest first");
     run_ragged<2>(s, "ragged 32..1024, longest first in groups of 32 x all heads");
+    run_ragged<2, 36>(s, "ragged, grouped, 4 workgroups per CU");
+    run_ragged<2, 48>(s, "ragged, grouped, 3 workgroups per CU");
+    run_ragged<2, 56>(s, "ragged, grouped, 2 workgroups per CU");
   }
   return 0;
 }
