@@ -202,6 +202,41 @@ def main():
                               (1, 8192, 4, 1), (1, 16384, 4, 1), (1, 2048, 4, 1), (2, 2048, 8, 1), (1, 4096, 32, 8)):
             for ns in (1, 2, 4, 8):
                 rows.append(prefill_case([L] * B, Hq, Hkv, num_splits=ns, iters=30))
+    if args.what in ("prefill_burn", "decode_burn"):   # one launch shape for ~6 s, for tools/power_probe.sh to sample beside
+        import time as _time
+        if args.what == "prefill_burn":
+            total = 4 * 4096
+            q = torch.randn(total, 32, D, device=dev).to(torch.bfloat16)
+            k = torch.randn(total, 8, D, device=dev).to(torch.bfloat16)
+            v = torch.randn(total, 8, D, device=dev).to(torch.bfloat16)
+            cu = torch.tensor([0, 4096, 8192, 12288, 16384], dtype=torch.int32, device=dev)
+            out = torch.empty_like(q)
+            fn = lambda: ops.prefill_attention(q, k, v, cu, cu, 4096, 4096, D ** -0.5, out=out)  # noqa: E731
+            unit = 4 * 4 * 32 * D * (4096 * 4096 - 4096 * 4095 // 2) / 1e12      # TFLOP per launch
+        else:
+            nblk = 256 * 4
+            kv = torch.empty(4, 2, nblk, BLOCK, 8, D, dtype=torch.bfloat16, device=dev).normal_()
+            q = torch.randn(256, 32, D, device=dev).to(torch.bfloat16)
+            bt = torch.randperm(nblk).to(torch.int32).view(256, 4).to(dev)
+            ctx_t = torch.full((256,), 1024, dtype=torch.int32, device=dev)
+            out = torch.empty_like(q)
+            st = {"i": 0}
+
+            def fn():
+                st["i"] += 1
+                ops.decode_attention(q, kv[st["i"] % 4, 0], kv[st["i"] % 4, 1], ctx_t, bt, D ** -0.5, out=out)
+            unit = 256 * 1024 * 8 * D * 4 / 1e12                                   # TB per launch
+        t_end = _time.perf_counter() + 6.0
+        n = 0
+        t0 = _time.perf_counter()
+        while _time.perf_counter() < t_end:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            n += 50
+        dt = _time.perf_counter() - t0
+        rows.append(dict(kind=args.what, launches=n, seconds=round(dt, 2), rate=round(n * unit / dt, 1),
+                         unit="TFLOP/s" if args.what == "prefill_burn" else "TB/s"))
     if args.what == "prefill_small":     # grids that fit the chip at once (TP = 8 shapes)
         for lens, Hq, Hkv in (([2048] * 8, 4, 1), ([4096] * 4, 4, 1), ([1024] * 16, 4, 1), ([4096] * 2, 8, 2),
                               ([1024] * 16, 32, 8), ([4096] * 4, 32, 8)):
