@@ -307,9 +307,11 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ forward
     @torch.inference_mode()
-    def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool):
+    def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool, greedy: bool = False):
+        """Logits of the step (rank 0; None elsewhere), or with `greedy` its argmax tokens (every rank)."""
+        head = self.model.greedy_tokens if greedy else self.model.compute_logits
         if is_prefill or self.enforce_eager or input_ids.size(0) > self.graph_bs[-1]:
-            return self.model.compute_logits(self.model(input_ids, positions))
+            return head(self.model(input_ids, positions))
         bs = input_ids.size(0)
         context = get_context()
         bucket = next(x for x in self.graph_bs if x >= bs)
@@ -330,10 +332,19 @@ class ModelRunner:
         else:
             gv["seq_order"][:1] = -1                        # nearly equal lengths: the kernel's default order
         self.graphs[bucket].replay()
-        return self.model.compute_logits(gv["outputs"][:bs])
+        return head(gv["outputs"][:bs])
 
-    def run(self, seqs: list[Sequence], is_prefill: bool):
+    def run(self, seqs: list[Sequence], is_prefill: bool, all_greedy: bool = False):
+        """all_greedy: rank 0 knows every sequence of the step samples at temperature 0 and says so
+        to the other ranks through this argument (sampling parameters do not travel with the step's
+        sequences). Under tensor parallelism the ranks then pick the token from per-shard maxima
+        instead of gathering [batch, vocab] logits to rank 0 (ParallelLMHead.greedy_tokens): the
+        same token, 16 bytes per sequence and rank on the wire instead of 2 * vocab / tp."""
         input_ids, positions = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
+        if all_greedy and self.world_size > 1:
+            tokens = self.run_model(input_ids, positions, is_prefill, greedy=True)
+            reset_context()
+            return tokens.tolist() if self.rank == 0 else None
         temperatures = self.prepare_sample(seqs) if self.rank == 0 else None
         logits = self.run_model(input_ids, positions, is_prefill)
         token_ids = None

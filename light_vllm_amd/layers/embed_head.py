@@ -68,3 +68,25 @@ class ParallelLMHead(VocabParallelEmbedding):
             parts = tp.gather_to_rank0(logits)
             logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
         return logits
+
+    def greedy_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """argmax over the whole vocabulary without gathering it: every rank takes the maximum of
+        its own shard, the ranks exchange one (value, index) pair per sequence (16 bytes instead of
+        2 * vocab / tp), and the largest value wins, the lowest rank on equal values. That is
+        exactly torch.argmax of the concatenated logits (first maximum), the token the reference's
+        sampler returns for temperature 0 (layers/sampler.py:60-64) from the logits its LM head
+        gathers to rank 0 (layers/embed_head.py:175-195) - here every rank ends up with it.
+        For steps whose sequences are all greedy; one rank: plain argmax."""
+        context = get_context()
+        if context.is_prefill:
+            last_indices = context.cu_seqlens_q[1:] - 1
+            x = x[last_indices].contiguous()
+        logits = F.linear(x, self.weight, self.bias).float()
+        value, index = logits.max(-1)               # first maximum of the shard
+        if self.tp_size == 1:
+            return index
+        # bf16 logits and indices below 2^24 are exact in float64; one small tensor, one collective
+        pair = torch.stack([value.double(), (index + self.vocab_start_idx).double()], -1)
+        pairs = tp.all_gather(pair)                 # [tp, B, 2]
+        best = pairs[..., 0].argmax(0)              # first maximum over ranks = lowest rank on ties
+        return pairs[best, torch.arange(pairs.size(1), device=pairs.device), 1].long()

@@ -51,6 +51,16 @@ def gather_to_rank0(t):
     return parts
 
 
+def all_gather(t):
+    """Every rank receives every rank's tensor, stacked in rank order on a new first axis. For the
+    few bytes per sequence of the sharded greedy pick (ParallelLMHead.greedy_tokens)."""
+    if _CARRIER is not None:
+        return _CARRIER.all_gather(t)
+    parts = [torch.empty_like(t) for _ in range(tp_size())]
+    dist.all_gather(parts, t)
+    return torch.stack(parts)
+
+
 def divide(numerator: int, denominator: int) -> int:
     assert numerator % denominator == 0, f"{numerator} is not divisible by {denominator}"
     return numerator // denominator

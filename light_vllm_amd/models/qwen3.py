@@ -146,3 +146,6 @@ class Qwen3ForCausalLM(nn.Module):
 
     def compute_logits(self, hidden_states):
         return self.lm_head(hidden_states)
+
+    def greedy_tokens(self, hidden_states):
+        return self.lm_head.greedy_tokens(hidden_states)

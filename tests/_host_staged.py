@@ -14,6 +14,12 @@ class HostStagedCarrier:
         t.copy_(h)
         return t
 
+    def all_gather(self, t):
+        h = t.cpu()
+        parts = [torch.empty_like(h) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, h)
+        return torch.stack(parts).to(t.device)
+
     def gather_to_rank0(self, t):
         rank0 = dist.get_rank() == 0
         h = t.cpu()

@@ -82,6 +82,23 @@ def _layers_worker(rank, world, port, out_dir):
         assert torch.allclose(logits, x[[1, 4]] @ we.T, atol=1e-5)
     else:
         assert logits is None
+    # sharded greedy pick: per-shard maxima + one (value, index) pair per sequence and rank; every
+    # rank gets torch.argmax of the full logits, also when two shards hold the same maximum
+    set_context(True, cu_seqlens_q=torch.tensor([0, 2, 5], dtype=torch.int32))
+    picked = head.greedy_tokens(x)
+    reset_context()
+    assert torch.equal(picked, (x[[1, 4]] @ we.T).argmax(-1))
+    we_tie = we.clone()
+    we_tie[V // world + 3] = we_tie[5]                       # the same row in both shards
+    xt = torch.stack([we_tie[5] * 3, we_tie[V - 1] * 3, we_tie[5] * 3])
+    head_tie = ParallelLMHead(V, E)
+    head_tie.weight.weight_loader(head_tie.weight, we_tie)
+    set_context(False)
+    picked = head_tie.greedy_tokens(xt)
+    reset_context()
+    full = xt @ we_tie.T
+    assert full[0, 5] == full[0, V // world + 3]            # a genuine tie across shards
+    assert torch.equal(picked, full.argmax(-1)) and picked[0].item() == 5
     open(os.path.join(out_dir, f"layers_ok_{rank}"), "w").close()
     dist.destroy_process_group()
 
@@ -97,7 +114,7 @@ def _prompts(lens=(300, 40, 257)):
     return [torch.randint(0, 512, (n,), generator=g).tolist() for n in lens]
 
 
-def _generate(runner, cfg, max_tokens, lens=(300, 40, 257), trace=None):
+def _generate(runner, cfg, max_tokens, lens=(300, 40, 257), trace=None, all_greedy=False):
     from light_vllm_amd.engine.scheduler import Scheduler
     from light_vllm_amd.engine.sequence import Sequence
     from light_vllm_amd.sampling_params import SamplingParams
@@ -110,7 +127,7 @@ def _generate(runner, cfg, max_tokens, lens=(300, 40, 257), trace=None):
         batch, is_prefill = sch.schedule()
         if trace is not None:
             trace.append((is_prefill, [(seqs.index(s), s.num_completion_tokens) for s in batch]))
-        toks = runner.call("run", batch, is_prefill)
+        toks = runner.call("run", batch, is_prefill, all_greedy)
         sch.postprocess(batch, toks)
     return [list(s.completion_token_ids) for s in seqs]
 
@@ -125,9 +142,11 @@ def _engine_worker(rank, world, port, event, out_dir):
     with cpu_kernels():
         if rank == 0:
             runner = ModelRunner(cfg, 0, [event])
-            out = _generate(runner, cfg, max_tokens=6)
+            out = _generate(runner, cfg, max_tokens=6)                        # logits gathered to rank 0
+            out_sharded = _generate(runner, cfg, max_tokens=6, all_greedy=True)  # per-shard maxima exchanged
             runner.call("exit")
             torch.save(out, os.path.join(out_dir, "tp2.pt"))
+            torch.save(out_sharded, os.path.join(out_dir, "tp2_sharded.pt"))
         else:
             ModelRunner(cfg, rank, event)      # serves the step RPC until "exit"
 
@@ -152,6 +171,7 @@ def test_tp2_engine_matches_tp1(tmp_path):
         runner = ModelRunner(cfg, 0, [])
         tp1 = _generate(runner, cfg, max_tokens=6)
     assert tp2 == tp1
+    assert torch.load(os.path.join(str(tmp_path), "tp2_sharded.pt")) == tp1
 
 
 # ------------------------------------------------------------------ preemption under TP

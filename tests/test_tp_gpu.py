@@ -119,7 +119,8 @@ def _worker_lagcopy(rank, world, port, event, out_path):
         sch.add(s)
     while not sch.is_finished():
         batch, is_prefill = sch.schedule()
-        sch.postprocess(batch, runner.call("run", batch, is_prefill))
+        # every sequence is greedy: the ranks exchange per-shard maxima instead of gathering logits
+        sch.postprocess(batch, runner.call("run", batch, is_prefill, True))
     runner.call("exit")
     with open(out_path, "w") as f:
         json.dump([list(s.completion_token_ids) for s in seqs], f)
