@@ -74,7 +74,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         its own shard, the ranks exchange one (value, index) pair per sequence (16 bytes instead of
         2 * vocab / tp), and the largest value wins, the lowest rank on equal values. That is
         exactly torch.argmax of the concatenated logits (first maximum), the token the reference's
-        sampler returns for temperature 0 (layers/sampler.py:60-64) from the logits its LM head
+        sampler returns for temperature 0 (layers/sampler.py:33, 64) from the logits its LM head
         gathers to rank 0 (layers/embed_head.py:175-195) - here every rank ends up with it.
         For steps whose sequences are all greedy; one rank: plain argmax."""
         context = get_context()
