@@ -6,21 +6,26 @@
 //
 //     [ flags: start[block][rank] ]  [ staging, parity 0 ]  [ staging, parity 1 ]
 //
-// One kernel per rank and call ("one shot"). Workgroup b of every rank owns slice b of the message:
-//   1. copies its slice of the input into this rank's staging buffer (parity = sequence number & 1),
+// One kernel per rank and call ("one shot"). Workgroup b of every rank owns slice b of the message
+// and region b of every staging buffer (1/64 of it, whatever the message length: a workgroup's
+// staging bytes never lie in another workgroup's region, in this call or any other):
+//   1. copies its slice of the input into region b of this rank's staging buffer (parity =
+//      sequence number & 1),
 //   2. makes the copy visible (system-scope release), then one lane per peer writes the sequence
 //      number into start[b][this rank] of THAT peer's flags (a remote 4-byte store over xGMI),
 //   3. one lane per peer polls this rank's own start[b][peer] until it has reached the sequence
 //      number (bounded by a wall-clock timeout), workgroup barrier, system-scope acquire,
 //   4. reads slice b of every rank's staging buffer (remote 16-byte loads, all in flight together),
 //      adds them in fp32 in rank order and writes the bf16 sum over the input.
-// There is no second barrier: the two staging parities make it unnecessary. A rank can overwrite
-// parity p only two calls later, and it can pass the wait of the call in between only after every
-// peer has entered that call, i.e. has finished the kernel that read parity p (kernels of one rank
-// run in stream order). A peer can be at most one call ahead, hence the ">=" in the poll.
+// There is no second barrier: the two staging parities make it unnecessary. Workgroup b can
+// overwrite parity p of its region only two of ITS calls later, and it can pass the wait of the
+// call in between only after every peer's workgroup b has entered that call, i.e. the peer has
+// finished the kernel that read parity p of region b (kernels of one rank run in stream order).
+// A peer can be at most one call ahead, hence the ">=" in the poll.
 // The sequence numbers are per workgroup and live in device memory, the kernel increments them
-// itself: a captured hipGraph replays correctly, and no workgroup ever waits for another
-// workgroup of its own rank.
+// itself: a captured hipGraph replays correctly, no workgroup ever waits for another workgroup of
+// its own rank, and calls of different lengths (which use different numbers of workgroups) mix
+// freely because a workgroup's parity only ever guards its own fixed region.
 //
 // "Two shot" for larger messages on many ranks (one shot reads (n-1) x the message per rank):
 // after the same publish + wait, rank r sums only sub-slice r of slice b over all ranks and writes
@@ -43,6 +48,7 @@ constexpr int kCommMaxBlocks = 64;
 constexpr size_t kCommBlockBytes = 8192;     // message bytes per workgroup before the grid stops growing
 constexpr size_t kCommFlagBytes = 4096;      // start[64][8] words = 2 KiB, padded
 constexpr size_t kCommAllocBytes = kCommFlagBytes + 2 * static_cast<size_t>(LV_COMM_MAX_BYTES);
+constexpr size_t kCommRegionVecs = LV_COMM_MAX_BYTES / 16 / kCommMaxBlocks;   // staging region of one workgroup, 16-byte units
 
 struct CommFlags {
   uint32_t start[kCommMaxBlocks][LV_COMM_MAX_RANKS];   // "rank r has published slice b of call e"
@@ -110,13 +116,15 @@ __global__ __launch_bounds__(256) void allreduce_kernel(const CommParams p) {
   const uint32_t epoch = s_epoch;
   const size_t parity_off = kCommFlagBytes + static_cast<size_t>(epoch & 1u) * LV_COMM_MAX_BYTES;
 
-  const size_t per = (p.nvec + gridDim.x - 1) / gridDim.x;
+  const size_t per = (p.nvec + gridDim.x - 1) / gridDim.x;   // <= kCommRegionVecs (host-checked)
   const size_t lo = static_cast<size_t>(b) * per;
   const size_t hi = lo + per < p.nvec ? lo + per : p.nvec;
+  // message element i of this slice is staged at reg + i of every rank's buffer
+  const ptrdiff_t reg = static_cast<ptrdiff_t>(b * kCommRegionVecs) - static_cast<ptrdiff_t>(lo);
 
   // 1. publish this rank's slice
   {
-    u32x4* mine = reinterpret_cast<u32x4*>(p.base[p.rank] + parity_off);
+    u32x4* mine = reinterpret_cast<u32x4*>(p.base[p.rank] + parity_off) + reg;
     const u32x4* src = reinterpret_cast<const u32x4*>(p.data);
     for (size_t i = lo + tid; i < hi; i += 256) mine[i] = src[i];
   }
@@ -142,17 +150,17 @@ __global__ __launch_bounds__(256) void allreduce_kernel(const CommParams p) {
     if constexpr (WORLD > 0) {
       u32x4 v[WORLD];
 #pragma unroll
-      for (int r = 0; r < WORLD; ++r) v[r] = reinterpret_cast<const u32x4*>(p.base[r] + parity_off)[i];
+      for (int r = 0; r < WORLD; ++r) v[r] = (reinterpret_cast<const u32x4*>(p.base[r] + parity_off) + reg)[i];
 #pragma unroll
       for (int r = 0; r < WORLD; ++r) add_bf16x8(acc, v[r]);
     } else {
-      for (int r = 0; r < world; ++r) add_bf16x8(acc, reinterpret_cast<const u32x4*>(p.base[r] + parity_off)[i]);
+      for (int r = 0; r < world; ++r) add_bf16x8(acc, (reinterpret_cast<const u32x4*>(p.base[r] + parity_off) + reg)[i]);
     }
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(acc[2 * j], acc[2 * j + 1]);
     if constexpr (TWO_SHOT) {
-      for (int r = 0; r < world; ++r) reinterpret_cast<u32x4*>(p.base[r] + parity_off)[i] = o;
+      for (int r = 0; r < world; ++r) (reinterpret_cast<u32x4*>(p.base[r] + parity_off) + reg)[i] = o;
     } else {
       dst[i] = o;
     }
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void allreduce_kernel(const CommParams p) {
     flag_exchange(p, world, b, tid, offsetof(CommFlags, done), epoch, s_failed);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    const u32x4* mine = reinterpret_cast<const u32x4*>(p.base[p.rank] + parity_off);
+    const u32x4* mine = reinterpret_cast<const u32x4*>(p.base[p.rank] + parity_off) + reg;
     for (size_t i = lo + tid; i < hi; i += 256) dst[i] = mine[i];
   }
 }
@@ -320,6 +328,8 @@ int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, int algorithm, lv
   p.world = c->world;
   size_t blocks = (bytes + kCommBlockBytes - 1) / kCommBlockBytes;
   if (blocks > static_cast<size_t>(kCommMaxBlocks)) blocks = kCommMaxBlocks;
+  if ((p.nvec + blocks - 1) / blocks > kCommRegionVecs)   // cannot happen within LV_COMM_MAX_BYTES; guards the region arithmetic
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce: slice of %zu bytes per workgroup exceeds its staging region", (p.nvec + blocks - 1) / blocks * 16);
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   // One shot moves (world - 1) x the message into every rank, two shot 2 (world - 1) / world of it in
