@@ -75,6 +75,20 @@ int lv_comm_connect(lv_comm_t* comm, const void* all_handles);
  */
 int lv_comm_all_reduce(lv_comm_t* comm, void* data, size_t count, int algorithm, lv_stream_t stream);
 
+/*
+ * The all-reduce followed by the residual add + RMSNorm the tensor-parallel layers run on its result
+ * (dist.all_reduce in RowParallelLinear.forward, layers/linear.py:388-389, then
+ * RMSNorm.add_rms_forward, layers/layernorm.py:52-80), in one kernel:
+ *   y = bf16(sum over ranks of x)   s = float(y) + float(residual)   residual = bf16(s)
+ *   x = bf16(s * rsqrt(mean(s^2) + eps)) * weight
+ * x, residual: [rows, hidden] bf16, contiguous, in place; weight: [hidden] bf16. Same bits as
+ * lv_comm_all_reduce(x) followed by lv_add_rms_norm(x, residual, weight). One exchange (the one-shot
+ * form): meant for the message sizes lv_comm_all_reduce serves in one shot. hidden: a multiple of 8
+ * up to 8192; rows * hidden * 2 <= LV_COMM_MAX_BYTES. The usual collective rules apply.
+ */
+int lv_comm_all_reduce_add_rms_norm(lv_comm_t* comm, void* x, void* residual, const void* weight, int64_t rows,
+                                    int hidden, float eps, lv_stream_t stream);
+
 /* 0 while healthy; non-zero once a kernel of this rank has given up waiting (host-visible word,
  * no device synchronisation). */
 int lv_comm_failed(lv_comm_t* comm);

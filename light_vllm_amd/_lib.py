@@ -31,6 +31,7 @@ SIGNATURES = {
     "lv_prefill_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                 c_int, c_int, c_int, c_float, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "lv_comm_all_reduce_add_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "lv_prefill_num_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "lv_prefill_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "lv_decode_num_splits": (c_int, [c_int, c_int, c_int, c_int]),

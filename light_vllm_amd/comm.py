@@ -58,6 +58,29 @@ class DirectAllReduce:
         _lib.check(rc, "lv_comm_all_reduce")
         return t
 
+    def usable_fused(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor) -> bool:
+        """x, residual [rows, hidden] and weight [hidden] fit all_reduce_add_rms_norm, and the message
+        is one the plain all-reduce would serve in one shot ((world - 1) * bytes <= 2 MiB)."""
+        if not (self.usable(x) and x.dim() == 2 and residual.shape == x.shape and residual.dtype == x.dtype
+                and residual.is_contiguous() and residual.device == x.device and residual.data_ptr() % 16 == 0):
+            return False
+        hidden = x.size(1)
+        nbytes = x.numel() * 2
+        return (weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == hidden
+                and weight.device == x.device and weight.data_ptr() % 16 == 0
+                and hidden % 8 == 0 and hidden <= 8192 and (self.world_size - 1) * nbytes <= (2 << 20))
+
+    def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+        """x <- RMSNorm(all_reduce(x) + residual) * weight, residual <- all_reduce(x) + residual, both in
+        place, one kernel; the same bits as all_reduce(x) followed by ops.add_rms_norm(x, residual, ...)."""
+        assert self.usable_fused(x, residual, weight), "fused all-reduce + norm: [rows, hidden] bf16, one-shot sized"
+        with torch.cuda.device(self.device):
+            rc = self._lib.lv_comm_all_reduce_add_rms_norm(self._comm, x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                                           x.size(0), x.size(1), float(eps),
+                                                           torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "lv_comm_all_reduce_add_rms_norm")
+        return x, residual
+
     def failed(self) -> bool:
         return self._comm is None or bool(self._lib.lv_comm_failed(self._comm))
 

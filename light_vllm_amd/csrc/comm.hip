@@ -177,6 +177,136 @@ __global__ __launch_bounds__(256) void allreduce_kernel(const CommParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The all-reduce above followed by the step every tensor-parallel layer runs on its result:
+// residual add + RMSNorm (reference: dist.all_reduce in RowParallelLinear.forward,
+// layers/linear.py:388-389, then RMSNorm.add_rms_forward, layers/layernorm.py:52-80). One kernel
+// instead of two and one pass less over [rows, hidden]. Workgroup b owns whole rows; after the
+// same publish + wait as the one-shot kernel it forms, per row,
+//     y = bf16(sum over ranks, fp32, rank order)         (what the all-reduce alone leaves in x)
+//     s = float(y) + float(residual);  residual = bf16(s)
+//     x = bf16(s * rsqrt(mean(s^2) + eps)) * weight
+// with the arithmetic, the element-to-lane mapping and the reduction tree of add_rms_norm_kernel
+// (csrc/fused_ops.hip), so the pair of calls and this kernel give the same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNormMaxChunks = 4;   // hidden <= 8 * 256 * 4
+
+struct CommNormParams {
+  CommParams c;            // c.data = x, c.nvec = rows * chunks
+  uint16_t* residual;
+  const uint16_t* weight;
+  int rows, chunks;        // chunks = hidden / 8 (16-byte units per row)
+  float eps, inv_hidden;
+};
+
+__device__ __forceinline__ float comm_round_bf16(float x) {
+  return __builtin_bit_cast(float, static_cast<u32>(f32_to_bf16_bits(x)) << 16);
+}
+
+template <int WORLD>
+__global__ __launch_bounds__(256) void allreduce_add_rms_norm_kernel(const CommNormParams q) {
+  const CommParams& p = q.c;
+  const int world = WORLD > 0 ? WORLD : p.world;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ uint32_t s_epoch;
+  __shared__ int s_failed;
+  __shared__ float wave_sums[2][4];
+  if (tid == 0) {
+    const uint32_t e = p.epoch[b] + 1;
+    p.epoch[b] = e;
+    s_epoch = e;
+    s_failed = *p.dev_failed;
+  }
+  __syncthreads();
+  const uint32_t epoch = s_epoch;
+  const size_t parity_off = kCommFlagBytes + static_cast<size_t>(epoch & 1u) * LV_COMM_MAX_BYTES;
+
+  const int rows_per = (q.rows + gridDim.x - 1) / gridDim.x;
+  const int r_lo = b * rows_per;
+  const int r_hi = r_lo + rows_per < q.rows ? r_lo + rows_per : q.rows;
+  const size_t lo = static_cast<size_t>(r_lo) * q.chunks;
+  const size_t hi = static_cast<size_t>(r_hi > r_lo ? r_hi : r_lo) * q.chunks;
+  const ptrdiff_t reg = static_cast<ptrdiff_t>(b * kCommRegionVecs) - static_cast<ptrdiff_t>(lo);
+
+  {
+    u32x4* mine = reinterpret_cast<u32x4*>(p.base[p.rank] + parity_off) + reg;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.data);
+    for (size_t i = lo + tid; i < hi; i += 256) mine[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  flag_exchange(p, world, b, tid, offsetof(CommFlags, start), epoch, s_failed);
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+
+  u32x4* xo = reinterpret_cast<u32x4*>(p.data);
+  u32x4* res = reinterpret_cast<u32x4*>(q.residual);
+  const u32x4* wgt = reinterpret_cast<const u32x4*>(q.weight);
+  for (int row = r_lo; row < r_hi; ++row) {
+    const size_t row0 = static_cast<size_t>(row) * q.chunks;
+    float v[kNormMaxChunks][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < kNormMaxChunks; ++j) {
+      const int c = tid + j * 256;
+      if (c < q.chunks) {
+        const size_t i = row0 + c;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (WORLD > 0) {
+          u32x4 pv[WORLD];
+#pragma unroll
+          for (int r = 0; r < WORLD; ++r) pv[r] = (reinterpret_cast<const u32x4*>(p.base[r] + parity_off) + reg)[i];
+#pragma unroll
+          for (int r = 0; r < WORLD; ++r) add_bf16x8(acc, pv[r]);
+        } else {
+          for (int r = 0; r < world; ++r) add_bf16x8(acc, (reinterpret_cast<const u32x4*>(p.base[r] + parity_off) + reg)[i]);
+        }
+        const u32x4 rv = res[i];
+        const u32 rw[4] = {rv.x, rv.y, rv.z, rv.w};
+        u32 nw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // the all-reduce's rounding to bf16, then the residual add in fp32
+          v[j][2 * k] = __fadd_rn(comm_round_bf16(acc[2 * k]), bf16_lo(rw[k]));
+          v[j][2 * k + 1] = __fadd_rn(comm_round_bf16(acc[2 * k + 1]), bf16_hi(rw[k]));
+          nw[k] = pack_bf16x2(v[j][2 * k], v[j][2 * k + 1]);
+        }
+        u32x4 nr;
+        nr.x = nw[0]; nr.y = nw[1]; nr.z = nw[2]; nr.w = nw[3];
+        res[i] = nr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += v[j][k] * v[j][k];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
+    float* ws = wave_sums[(row - r_lo) & 1];     // two sets: the next row's writes cannot overtake this row's reads
+    if ((tid & 63) == 0) ws[tid >> 6] = sq;
+    __syncthreads();
+    const float total = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    const float rn = rsqrtf(__fadd_rn(total * q.inv_hidden, q.eps));
+#pragma unroll
+    for (int j = 0; j < kNormMaxChunks; ++j) {
+      const int c = tid + j * 256;
+      if (c < q.chunks) {
+        const u32x4 wv = wgt[c];
+        const u32 ww[4] = {wv.x, wv.y, wv.z, wv.w};
+        u32 ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float lo_ = __fmul_rn(comm_round_bf16(__fmul_rn(v[j][2 * k], rn)), bf16_lo(ww[k]));
+          const float hi_ = __fmul_rn(comm_round_bf16(__fmul_rn(v[j][2 * k + 1], rn)), bf16_hi(ww[k]));
+          ow[k] = pack_bf16x2(lo_, hi_);
+        }
+        u32x4 ov;
+        ov.x = ow[0]; ov.y = ow[1]; ov.z = ow[2]; ov.w = ow[3];
+        xo[row0 + c] = ov;
+      }
+    }
+  }
+}
+
 }  // namespace lv
 
 using namespace lv;
@@ -355,6 +485,59 @@ int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, int algorithm, lv
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "all_reduce launch: %s", hipGetErrorString(e));
+  return LV_OK;
+}
+
+int lv_comm_all_reduce_add_rms_norm(lv_comm_t* c, void* x, void* residual, const void* weight, int64_t rows,
+                                    int hidden, float eps, lv_stream_t stream) {
+  if (!c) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce_add_rms_norm: null communicator");
+  if (!c->connected) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce_add_rms_norm: communicator not connected");
+  if (lv_comm_failed(c))
+    return fail(LV_ERR_COMM, "all_reduce_add_rms_norm: rank %d gave up waiting for a peer in an earlier call; the communicator is dead", c->rank);
+  if (rows == 0) return LV_OK;
+  if (!x || !residual || !weight) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce_add_rms_norm: null pointer");
+  if (rows < 0 || hidden <= 0 || hidden % 8 != 0 || hidden > 8 * 256 * kNormMaxChunks)
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce_add_rms_norm: %lld rows of %d (hidden: a multiple of 8 up to %d)",
+                static_cast<long long>(rows), hidden, 8 * 256 * kNormMaxChunks);
+  if (!(eps > 0.f) || !(eps < 1.f)) return fail(LV_ERR_INVALID_ARGUMENT, "all_reduce_add_rms_norm: eps %g", eps);
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(weight)) & 15u) != 0)
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce_add_rms_norm: 16-byte alignment required");
+  const size_t bytes = static_cast<size_t>(rows) * hidden * 2;
+  if (bytes > LV_COMM_MAX_BYTES)
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce_add_rms_norm: %zu bytes exceed the %u-byte limit of the direct path", bytes,
+                static_cast<unsigned>(LV_COMM_MAX_BYTES));
+  const int chunks = hidden / 8;
+  int64_t blocks = rows < kCommMaxBlocks ? rows : kCommMaxBlocks;
+  const int64_t rows_per = (rows + blocks - 1) / blocks;
+  if (static_cast<size_t>(rows_per) * chunks > kCommRegionVecs)   // cannot happen within LV_COMM_MAX_BYTES
+    return fail(LV_ERR_UNSUPPORTED, "all_reduce_add_rms_norm: %lld rows per workgroup exceed its staging region",
+                static_cast<long long>(rows_per));
+  CommNormParams q;
+  q.c.data = static_cast<uint16_t*>(x);
+  q.c.nvec = static_cast<size_t>(rows) * chunks;
+  for (int r = 0; r < LV_COMM_MAX_RANKS; ++r) q.c.base[r] = r < c->world ? c->base[r] : nullptr;
+  q.c.epoch = c->epoch;
+  q.c.dev_failed = c->dev_failed;
+  q.c.host_failed = c->host_failed_dev;
+  q.c.timeout_ticks = c->timeout_ticks;
+  q.c.rank = c->rank;
+  q.c.world = c->world;
+  q.residual = static_cast<uint16_t*>(residual);
+  q.weight = static_cast<const uint16_t*>(weight);
+  q.rows = static_cast<int>(rows);
+  q.chunks = chunks;
+  q.eps = eps;
+  q.inv_hidden = static_cast<float>(1.0 / hidden);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (c->world) {
+    case 2: hipLaunchKernelGGL((allreduce_add_rms_norm_kernel<2>), grid, block, 0, s, q); break;
+    case 4: hipLaunchKernelGGL((allreduce_add_rms_norm_kernel<4>), grid, block, 0, s, q); break;
+    case 8: hipLaunchKernelGGL((allreduce_add_rms_norm_kernel<8>), grid, block, 0, s, q); break;
+    default: hipLaunchKernelGGL((allreduce_add_rms_norm_kernel<0>), grid, block, 0, s, q); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "all_reduce_add_rms_norm launch: %s", hipGetErrorString(e));
   return LV_OK;
 }
 

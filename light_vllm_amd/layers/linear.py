@@ -124,8 +124,14 @@ class RowParallelLinear(LinearBase):
         shard = param.data.size(self.tp_dim)
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, reduce: bool = True) -> torch.Tensor:
+        """reduce=False leaves this rank's partial sums: the caller reduces them together with the
+        step that follows (layers.tp.all_reduce_add_rms_norm). Not with a bias, which is added once,
+        after the sum."""
         y = F.linear(x, self.weight)
+        if not reduce:
+            assert self.bias is None
+            return y
         if self.tp_size > 1:
             tp.all_reduce(y)
         if self.bias is not None:

@@ -7,6 +7,7 @@ import torch
 import torch.distributed as dist
 
 from .. import comm as _comm
+from . import fused as _fused
 
 
 def tp_rank() -> int:
@@ -39,6 +40,19 @@ def all_reduce(t):
         return _CARRIER.all_reduce(t)
     dist.all_reduce(t)
     return t
+
+
+def all_reduce_add_rms_norm(x, residual, norm):
+    """norm(all_reduce(x), residual) for a RowParallelLinear output that has not been reduced yet
+    (reference: layers/linear.py:388-389 followed by layers/layernorm.py:53-80). One kernel on the
+    direct path for messages it serves in one shot; otherwise the two steps one after the other.
+    Returns (normed x, new residual)."""
+    if tp_size() > 1:
+        direct = _comm.active()
+        if direct is not None and _fused.use_fused(x) and direct.usable_fused(x, residual, norm.weight):
+            return direct.all_reduce_add_rms_norm(x, residual, norm.weight, norm.eps)
+        all_reduce(x)
+    return norm(x, residual)
 
 
 def gather_to_rank0(t):

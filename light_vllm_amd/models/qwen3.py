@@ -19,6 +19,7 @@ from ..layers.layernorm import RMSNorm
 from ..layers.fused import use_fused
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.rotary_embedding import get_rope
+from ..layers import tp
 from ..layers.tp import divide, tp_size
 from ..utils.context import get_context
 
@@ -44,7 +45,7 @@ class Qwen3Attention(nn.Module):
         self.q_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
         self.k_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
 
-    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, reduce: bool = True) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if use_fused(qkv):
@@ -56,12 +57,12 @@ class Qwen3Attention(nn.Module):
                                    self.q_norm.weight, self.k_norm.weight, self.q_norm.eps,
                                    self.rotary_emb.cos_sin_cache, attn.k_cache, attn.v_cache,
                                    get_context().slot_mapping)
-            return self.o_proj(attn(q, k, v, kv_stored=True))
+            return self.o_proj(attn(q, k, v, kv_stored=True), reduce)
         q = self.q_norm(q.view(-1, self.num_heads, self.head_dim)).view(q.shape)
         k = self.k_norm(k.view(-1, self.num_kv_heads, self.head_dim)).view(k.shape)
         q, k = self.rotary_emb(positions, q, k)
         o = self.attn(q, k, v)
-        return self.o_proj(o)
+        return self.o_proj(o, reduce)
 
 
 class Qwen3MLP(nn.Module):
@@ -73,8 +74,8 @@ class Qwen3MLP(nn.Module):
         self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False)
         self.act_fn = SiluAndMul()
 
-    def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+    def forward(self, x, reduce: bool = True):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)), reduce)
 
 
 class Qwen3DecoderLayer(nn.Module):
@@ -97,14 +98,19 @@ class Qwen3DecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, positions, hidden_states, residual):
-        if residual is None:
+        """Same operations in the same order as the reference layer (models/qwen3.py:206-230). Under
+        tensor parallelism the two row-parallel projections hand over their partial sums and the
+        all-reduce runs together with the residual add + RMSNorm that consumes it
+        (tp.all_reduce_add_rms_norm); the layer therefore RETURNS partial sums, which the next
+        layer's input norm (or the model's final norm) reduces."""
+        if residual is None:        # first layer: the embedding output is complete
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
-            hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(positions, hidden_states)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        hidden_states = self.mlp(hidden_states)
+            hidden_states, residual = tp.all_reduce_add_rms_norm(hidden_states, residual, self.input_layernorm)
+        hidden_states = self.self_attn(positions, hidden_states, reduce=False)
+        hidden_states, residual = tp.all_reduce_add_rms_norm(hidden_states, residual, self.post_attention_layernorm)
+        hidden_states = self.mlp(hidden_states, reduce=False)
         return hidden_states, residual
 
 
@@ -121,7 +127,7 @@ class Qwen3Model(nn.Module):
         residual = None
         for layer in self.layers:
             hidden_states, residual = layer(positions, hidden_states, residual)
-        hidden_states, _ = self.norm(hidden_states, residual)
+        hidden_states, _ = tp.all_reduce_add_rms_norm(hidden_states, residual, self.norm)
         return hidden_states
 
 

@@ -22,7 +22,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
         "lv_prefill_num_splits", "lv_prefill_workspace_bytes",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
-        "lv_comm_destroy"])
+        "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm"])
 
 
 def test_library_exports_every_declared_symbol():
@@ -128,6 +128,7 @@ def test_comm_argument_validation_without_a_device():
     assert lib.lv_comm_create(0, 2, -1, ctypes.byref(comm)) == -1
     assert lib.lv_comm_create(0, 2, 0, None) == -1
     assert lib.lv_comm_all_reduce(None, None, 8, 0, None) == -1
+    assert lib.lv_comm_all_reduce_add_rms_norm(None, None, None, None, 4, 4096, 1e-6, None) == -1
     assert lib.lv_comm_get_handle(None, None) == -1 and lib.lv_comm_connect(None, None) == -1
     assert lib.lv_comm_failed(None) == 1 and lib.lv_comm_destroy(None) == 0
     assert lib.lv_error_string(-5) == b"communicator failure"

@@ -70,6 +70,56 @@ def _worker(rank, world, port, out_dir, rounds):
     if not torch.equal(y.cpu().view(-1).view(torch.int16), _expected(parts).view(torch.int16)):
         res["bad"].append(("tp.all_reduce",))
     lvcomm.install(None)
+    # all-reduce + residual add + RMSNorm in one kernel: the bits of the two steps one after the other
+    from light_vllm_amd import ops
+    res["fused_cases"] = 0
+    for case, (rows, hidden) in enumerate([(1, 4096), (8, 4096), (33, 4096), (65, 4096), (256, 4096), (7, 1024), (3, 5120), (2, 8192)]):
+        g = torch.Generator().manual_seed(4000 + case)
+        parts = [(torch.randn(rows, hidden, generator=g) * (1 + 0.25 * r)).to(torch.bfloat16) for r in range(world)]
+        residual = torch.randn(rows, hidden, generator=g).to(torch.bfloat16)
+        weight = (1 + 0.1 * torch.randn(hidden, generator=g)).to(torch.bfloat16).to(dev)
+        x_two, r_two = parts[rank].to(dev), residual.to(dev)
+        if not c.usable_fused(x_two, r_two, weight):       # beyond the one-shot sizes at this rank count
+            continue
+        c.all_reduce(x_two, "one_shot")
+        out_two = ops.add_rms_norm(x_two, r_two, weight, 1e-6)
+        x_one, r_one = parts[rank].to(dev), residual.to(dev)
+        c.all_reduce_add_rms_norm(x_one, r_one, weight, 1e-6)
+        res["fused_cases"] += 1
+        if not (torch.equal(x_one.view(torch.int16), out_two.view(torch.int16)) and
+                torch.equal(r_one.view(torch.int16), r_two.view(torch.int16))):
+            res["bad"].append(("fused", rows, hidden))
+        if not torch.equal(r_two.cpu().view(torch.int16),
+                           (_expected([p.view(-1) for p in parts]).view(rows, hidden).float() + residual.float())
+                           .to(torch.bfloat16).view(torch.int16)):
+            res["bad"].append(("fused residual vs host", rows, hidden))
+    # what the fusion saves, under graph replay (the host's per-call cost out of the picture): [32, 4096]
+    xt = torch.zeros(32, 4096, dtype=torch.bfloat16, device=dev)
+    rt = torch.zeros(32, 4096, dtype=torch.bfloat16, device=dev)
+    wt = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+    ot = torch.empty_like(xt)
+    timings = {}
+    for name, fn in (("two_kernels", lambda: (c.all_reduce(xt, "one_shot"), ops.add_rms_norm(xt, rt, wt, 1e-6, out=ot))),
+                     ("one_kernel", lambda: c.all_reduce_add_rms_norm(xt, rt, wt, 1e-6))):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        gt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gt):
+            for _ in range(20):
+                fn()
+        gt.replay()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            gt.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        timings[name] = e0.elapsed_time(e1) * 1e3 / 200
+        dist.barrier()
+    res["fused_timing_us"] = timings
     # hipGraph: three all-reduces on static buffers, replayed on new contents
     bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for n in (4096, 64 * 4096, 8 * 37)]
     for b in bufs:
@@ -134,8 +184,11 @@ def test_direct_all_reduce_shared_gpu(gpu, tmp_path, world):
         assert not res["bad"], f"rank {r}: {res['bad'][:5]}"
         assert res["calls"] == rounds * 2 * len(SIZES)
         assert res["failed_after_use"] is False
+        assert res["fused_cases"] >= (3 if world == 8 else 6)
         if r == 0:
-            print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms")
+            print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms; [32, 4096] all-reduce + add + RMSNorm "
+                  f"under graph replay: {res['fused_timing_us']['two_kernels']:.1f} us as two kernels, "
+                  f"{res['fused_timing_us']['one_kernel']:.1f} us as one")
             assert res["dead"] is True
             assert 250 <= res["timeout_ms"] <= 5000
             assert "communicator" in res["second_call"]
