@@ -278,6 +278,10 @@ def main():
         rows.append(decode_case(64, 4096, 32, 8, graph=True))
     if args.what == "decode_g8":
         rows.append(decode_case(256, 1024, 64, 8))
+    if args.what == "decode_ragged1":    # ragged batches, one pass, graph replay: for comparing builds
+        for (Hq, Hkv) in [(32, 8), (16, 8), (64, 8)]:
+            for ctx in (1024, 4096):
+                rows.append(decode_case(256, ctx, Hq, Hkv, nsplit=1, ragged=True, ordered=True, graph=True))
     if args.what == "decode_ragged":
         for (Hq, Hkv) in [(32, 8), (16, 8)]:
             for ns in (1, 2, 4, 8):
