@@ -174,3 +174,24 @@ def test_prefill_split_kv_spiked_and_bit_stable(gpu):
     a = _check(gpu, case, num_splits=6)
     b = _run(gpu, case, num_splits=6)
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("num_splits", [0, 1, 4])
+def test_prefill_sequence_without_new_tokens(gpu, num_splits):
+    """A fully cached prompt leaves its sequence with no query rows (cu_seqlens_q repeats a value;
+    the reference does not special-case it either, engine/model_runner.py:318-328). The launch
+    must neither read nor write anything for it and the other sequences must come out as always,
+    whether it sits first, in the middle or last, and with KV runs."""
+    lens_k = [512, 600, 256, 1024, 768]
+    cached = [512, 256, 256, 768, 768]
+    lens_q = [k - c for k, c in zip(lens_k, cached)]          # [0, 344, 0, 256, 0]
+    case = make_prefill_case(61, lens_q, lens_k, 32, 8, paged=True)
+    d = to_dev(case, gpu)
+    from light_vllm_amd import ops
+    out = torch.full((sum(lens_q) + 8, 32, 128), 7.0, dtype=torch.bfloat16, device=gpu)   # 8 canary rows behind the output
+    ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                          block_table=d["block_table"], num_splits=num_splits, out=out[:sum(lens_q)])
+    torch.cuda.synchronize()
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"], case["block_table"])
+    assert (out[:sum(lens_q)].float().cpu() - ref).abs().max().item() <= TOL
+    assert bool((out[sum(lens_q):] == 7.0).all())
