@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 7
+#define LV_ABI_VERSION 8
 
 /* kernel_hint of lv_decode_attn: which of the two decode kernels serves the call. */
 #define LV_DECODE_KERNEL_AUTO 0   /* by num_heads / num_kv_heads: vector-ALU for 1-2, matrix-core for 3-8 */
@@ -178,6 +178,20 @@ int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_str
  *   sufficient workspace is given), 1 = one pass, up to 32. total_q = rows of q (needed with
  *   num_splits != 1). Results agree with the one-pass kernels to bf16 rounding (different
  *   summation order). The workspace rule of lv_decode_attn applies: one stream per workspace.
+ *   Rows of q at or past cu_seqlens_q[batch] (a padded q) are left untouched by every path.
+ * tile_order / tile_order_len / tile_order_rows: optional launch order of the query tiles, built by a
+ *   caller that has the sequence lengths on the host (NULL = the library's own mapping from the
+ *   static shape; results never depend on it). A query tile is tile_order_rows consecutive query
+ *   rows of one sequence, tile t of a sequence starting at row t * tile_order_rows;
+ *   tile_order_rows must equal lv_prefill_tile_rows(max_seqlen_q, num_splits, kernel_hint). The
+ *   table is int32 [tile_order_len / C][C] with C = lv_prefill_order_columns(num_kv_heads); an entry
+ *   is b * ceil(max_seqlen_q / tile_order_rows) + t, or negative for an empty place. Every tile of
+ *   every sequence must appear exactly once (a tile that is left out is not computed). Column c's
+ *   entries run, for kv head h, on XCD (h + num_kv_heads * c) % 8, in table order from row 0: with
+ *   1, 2 or 4 kv heads per rank the library's own mapping spreads each sequence's K/V stream over
+ *   all XCDs, and a table that keeps a sequence's tiles in one or two columns lets an XCD's L2 fetch
+ *   the stream once; rows should go heaviest (most visible keys) first. No counterpart in the
+ *   reference call; light_vllm_amd/prefill_order.py builds such a table.
  */
 int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
@@ -186,7 +200,15 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     const int32_t* block_table, int block_table_stride, int block_size,
                     int num_heads, int num_kv_heads, int head_dim, float scale,
                     int64_t total_q, void* workspace, size_t workspace_bytes, int num_splits,
+                    const int32_t* tile_order, int tile_order_len, int tile_order_rows,
                     int kernel_hint, lv_stream_t stream);
+
+/* Query rows per tile of the kernel lv_prefill_attn runs for these arguments (128 or 256; 0 for an
+ * unknown kernel_hint). num_splits as resolved (lv_prefill_num_splits for 0). */
+int lv_prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint);
+
+/* Columns of a tile_order table: 8 / num_kv_heads for 1, 2 or 4 kv heads, else 1. */
+int lv_prefill_order_columns(int num_kv_heads);
 
 /* Split count lv_prefill_attn uses for num_splits == 0 on these static shapes. */
 int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads);

@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvattn.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> (restype, argtypes); must list every symbol include/*.h declares.
 SIGNATURES = {
@@ -30,7 +30,10 @@ SIGNATURES = {
     "lv_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "lv_prefill_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
-                                c_int, c_int, c_int, c_float, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+                                c_int, c_int, c_int, c_float, c_int64, c_void_p, c_size_t, c_int,
+                                c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lv_prefill_tile_rows": (c_int, [c_int, c_int, c_int]),
+    "lv_prefill_order_columns": (c_int, [c_int]),
     "lv_comm_all_reduce_add_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "lv_prefill_num_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "lv_prefill_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),

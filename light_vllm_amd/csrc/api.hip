@@ -262,7 +262,8 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
                     int max_seqlen_q, int max_seqlen_k, const int32_t* block_table,
                     int block_table_stride, int block_size, int num_heads, int num_kv_heads,
                     int head_dim, float scale, int64_t total_q, void* workspace, size_t workspace_bytes,
-                    int num_splits, int kernel_hint, lv_stream_t stream) {
+                    int num_splits, const int32_t* tile_order, int tile_order_len, int tile_order_rows,
+                    int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || num_heads <= 0 || num_kv_heads <= 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "prefill: head_dim %d != 128", head_dim);
@@ -310,9 +311,11 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
   if (num_splits < 0 || num_splits > kMaxPrefillSplits)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: num_splits %d not in 0..%d", num_splits, kMaxPrefillSplits);
   int nsplit = num_splits == 0 ? prefill_heuristic_splits(batch, max_seqlen_q, max_seqlen_k, num_heads) : num_splits;
-  // the automatic choice falls back to one pass when the caller brought no workspace for it
+  // the automatic choice falls back to one pass when the caller brought no workspace for it (or
+  // did not say how many rows q has)
   if (num_splits == 0 && nsplit > 1 &&
-      (!workspace || workspace_bytes < lv_prefill_workspace_bytes(total_q, num_heads, head_dim, nsplit)))
+      (total_q <= 0 || !workspace ||
+       workspace_bytes < lv_prefill_workspace_bytes(total_q, num_heads, head_dim, nsplit)))
     nsplit = 1;
   p.nsplit = nsplit;
   p.ws_o = nullptr;
@@ -328,8 +331,28 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
     p.ws_ml = p.ws_o + static_cast<size_t>(total_q) * num_heads * nsplit * kHeadDim;
   }
   p.scale_log2e = scale * kLog2e;
+  p.tile_order = nullptr;
+  p.order_cols = 1;
+  p.order_len = 0;
+  p.order_rows = 0;
+  if (tile_order) {
+    const int cols = prefill_order_columns(num_kv_heads);
+    if (tile_order_len <= 0 || tile_order_len % cols != 0)
+      return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order_len %d must be a positive multiple of %d "
+                  "(lv_prefill_order_columns)", tile_order_len, cols);
+    p.tile_order = tile_order;
+    p.order_cols = cols;
+    p.order_len = tile_order_len;
+    p.order_rows = tile_order_rows;
+  }
   return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
 }
+
+int lv_prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint) {
+  return prefill_tile_rows(max_seqlen_q, num_splits, kernel_hint);
+}
+
+int lv_prefill_order_columns(int num_kv_heads) { return prefill_order_columns(num_kv_heads); }
 
 int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads) {
   return prefill_heuristic_splits(batch, max_seqlen_q, max_seqlen_k, num_heads);

@@ -37,7 +37,16 @@ struct PrefillParams {
   float* ws_ml;                // [total_q, Hq, nsplit, 2]   (row maximum in log2 units, row sum)
   int64_t total_q;
   float scale_log2e;
+  const int32_t* tile_order;   // optional [order_len / order_cols][order_cols] table of b * qtiles + t (< 0: empty)
+  int order_cols;              // columns of the table: 8 / num_kv_heads for 1, 2, 4 kv heads, else 1
+  int64_t order_len;
+  int order_rows;              // query rows per tile the table was built for (must match the kernel's)
 };
+
+// Query rows per workgroup tile of the prefill kernel a launch with these arguments runs.
+int prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint);
+// Columns of a tile_order table for this many kv heads.
+int prefill_order_columns(int num_kv_heads);
 
 struct QkNormRopeParams {
   uint16_t* q;              // [N, Hq, 128], updated in place

@@ -182,6 +182,49 @@ __device__ __forceinline__ void acc_scale(float alpha) {
                : "=&v"(t) : "v"(alpha), "n"(R));
 }
 
+// Workgroup index -> its share of the launch: kv head, KV run, query head, sequence, first query row.
+// Natural mapping (p.tile_order == nullptr): 1-D grid with the kv head fastest - workgroups are dealt
+// round-robin over the 8 XCDs, so with 8 kv heads every query tile and query head that reads one
+// (sequence, kv head)'s K/V runs on one XCD and shares its L2 - then KV run, query head within the
+// group, query tile (heaviest = last rows first), sequence.
+// With a caller-built order (the host knows the lengths): tile_order is a [rows][order_cols] table of
+// items b * qtiles + t (sequence b, query tile t; negative = empty), order_cols = 8 / kv heads when
+// that is 2, 4 or 8 and 1 otherwise. The workgroup index decomposes kv head fastest, then column,
+// so XCD = kv head + kv heads * column: a column's items all run on one XCD per kv head. With fewer
+// than 8 kv heads the natural mapping spreads every K/V stream over 8 / kv heads XCDs, each fetching
+// it from HBM for itself; a table that keeps a sequence inside one or two columns lets an XCD's L2
+// serve its stream once. Rows are taken in table order (heaviest first as the caller sorts them),
+// and every row is followed by all query heads of its group.
+struct TileWork { int kvh, split, hq, b, q0; };
+template <int BM>
+__device__ __forceinline__ bool tile_of_block(const PrefillParams& p, TileWork& w) {
+  const int G = p.num_heads / p.num_kv_heads;
+  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
+  int wg = blockIdx.x;
+  w.kvh = wg % p.num_kv_heads;
+  wg /= p.num_kv_heads;
+  if (p.tile_order == nullptr) {
+    w.split = wg % p.nsplit;
+    wg /= p.nsplit;
+    w.hq = w.kvh * G + wg % G;
+    wg /= G;
+    w.q0 = (qtiles - 1 - wg % qtiles) * BM;
+    w.b = wg / qtiles;
+    return true;
+  }
+  const int col = wg % p.order_cols;
+  wg /= p.order_cols;
+  w.split = wg % p.nsplit;
+  wg /= p.nsplit;
+  w.hq = w.kvh * G + wg % G;
+  wg /= G;
+  const int item = p.tile_order[static_cast<int64_t>(wg) * p.order_cols + col];
+  if (item < 0) return false;
+  w.b = item / qtiles;
+  w.q0 = (item % qtiles) * BM;
+  return w.b < p.batch;
+}
+
 // NW = waves per workgroup, RB = 32-row query blocks per wave (1); the workgroup's query tile is
 // 32*RB*NW rows, two waves per SIMD on compiler-allocated registers.
 // DMA = true stages K/V tiles HBM -> LDS directly (global_load_lds, no VGPRs, no ds_write).
@@ -196,24 +239,12 @@ void prefill_attn_kernel(const PrefillParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  // 1-D grid, kv head fastest: workgroups are dealt round-robin over the 8 XCDs, so with 8 (or 4,
-  // 2, 1) kv heads all query tiles and query heads that read one (sequence, kv head)'s K/V run on
-  // one XCD and share its L2. Then query head within the group, then query tile (heaviest = last
-  // rows first), then sequence.
   // With p.nsplit > 1 the key tiles of a query tile are cut into nsplit runs, one workgroup each
   // (few query tiles against a long context: a prefix-cached prompt, a short batch); the runs'
   // unnormalised outputs and (max, sum) go to the workspace and prefill_merge_kernel combines them.
-  const int G = p.num_heads / p.num_kv_heads;
-  int wg = blockIdx.x;
-  const int kvh = wg % p.num_kv_heads;
-  wg /= p.num_kv_heads;
-  const int split = wg % p.nsplit;
-  wg /= p.nsplit;
-  const int hq = kvh * G + wg % G;
-  wg /= G;
-  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
-  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
-  const int b = wg / qtiles;
+  TileWork tw;
+  if (!tile_of_block<BM>(p, tw)) return;
+  const int kvh = tw.kvh, split = tw.split, hq = tw.hq, q0 = tw.q0, b = tw.b;
   const int q_start = p.cu_q[b];
   const int Lq = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
@@ -668,15 +699,9 @@ void prefill_pp_kernel(const PrefillParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  const int G = p.num_heads / p.num_kv_heads;
-  int wg = blockIdx.x;
-  const int kvh = wg % p.num_kv_heads;
-  wg /= p.num_kv_heads;
-  const int hq = kvh * G + wg % G;
-  wg /= G;
-  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
-  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
-  const int b = wg / qtiles;
+  TileWork tw;
+  if (!tile_of_block<BM>(p, tw)) return;   // launched with nsplit == 1
+  const int kvh = tw.kvh, hq = tw.hq, q0 = tw.q0, b = tw.b;
   const int q_start = p.cu_q[b];
   const int Lq = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
@@ -1127,15 +1152,9 @@ void prefill_w64_kernel(const PrefillParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTileBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  const int G = p.num_heads / p.num_kv_heads;
-  int wg = blockIdx.x;
-  const int kvh = wg % p.num_kv_heads;
-  wg /= p.num_kv_heads;
-  const int hq = kvh * G + wg % G;
-  wg /= G;
-  const int qtiles = (p.max_seqlen_q + BM - 1) / BM;
-  const int q0 = (qtiles - 1 - wg % qtiles) * BM;
-  const int b = wg / qtiles;
+  TileWork tw;
+  if (!tile_of_block<BM>(p, tw)) return;   // launched with nsplit == 1
+  const int kvh = tw.kvh, hq = tw.hq, q0 = tw.q0, b = tw.b;
   const int q_start = p.cu_q[b];
   const int Lq = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
@@ -1621,11 +1640,15 @@ void prefill_w64_kernel(const PrefillParams p) {
 __global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restrict__ ws_o,
                                                             const float* __restrict__ ws_ml,
                                                             uint16_t* __restrict__ o, int64_t o_stride0,
-                                                            int num_heads, int nsplit, int64_t pairs) {
+                                                            int num_heads, int nsplit, int64_t pairs,
+                                                            const int32_t* __restrict__ cu_q, int batch) {
   const int64_t pair = static_cast<int64_t>(blockIdx.x) * 8 + (threadIdx.x >> 5);
   if (pair >= pairs) return;
   const int ln = threadIdx.x & 31;
   const int64_t row = pair / num_heads;
+  // rows of q past the last sequence (a padded q) have no partials: like the one-pass kernels,
+  // leave their output rows untouched
+  if (row >= cu_q[batch]) return;
   const int hq = static_cast<int>(pair % num_heads);
   const int64_t base = pair * nsplit;
   float M = -INFINITY;
@@ -1651,31 +1674,61 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(const float* __restr
   *reinterpret_cast<u32x2*>(o + row * o_stride0 + hq * kHeadDim + 4 * ln) = w;
 }
 
+// (sequence, query tile) items of the launch: the caller's table (empty entries included), or every
+// tile of every sequence up to max_seqlen_q
+static int64_t grid_items(const PrefillParams& p, int bm) {
+  if (p.tile_order) return p.order_len;
+  return static_cast<int64_t>((p.max_seqlen_q + bm - 1) / bm) * p.batch;
+}
+
 template <bool PAGED>
 static void launch_w64(const PrefillParams& p, hipStream_t stream) {
-  const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
-  const int64_t total = qtiles * p.num_heads * p.batch;
+  const int64_t total = grid_items(p, 256) * p.num_heads;
   hipLaunchKernelGGL((prefill_w64_kernel<PAGED>), dim3(static_cast<unsigned>(total)), dim3(256), 0, stream, p);
 }
 
 template <bool PAGED>
 static void launch_pp(const PrefillParams& p, hipStream_t stream) {
-  const int64_t qtiles = (p.max_seqlen_q + 255) / 256;
-  const int64_t total = qtiles * p.num_heads * p.batch;
+  const int64_t total = grid_items(p, 256) * p.num_heads;
   hipLaunchKernelGGL((prefill_pp_kernel<PAGED>), dim3(static_cast<unsigned>(total)), dim3(512), 0, stream, p);
 }
 
 template <bool PAGED, int NW, int RB, bool DMA>
 static void launch_cfg(const PrefillParams& p, hipStream_t stream) {
   constexpr int BM = 32 * RB * NW;
-  const int64_t qtiles = (p.max_seqlen_q + BM - 1) / BM;
-  const int64_t total = qtiles * p.num_heads * p.batch * p.nsplit;
+  const int64_t total = grid_items(p, BM) * p.num_heads * p.nsplit;
   hipLaunchKernelGGL((prefill_attn_kernel<PAGED, NW, RB, DMA>), dim3(static_cast<unsigned>(total)), dim3(64 * NW), 0,
                      stream, p);
 }
 
+// Kernel configuration of a launch: 0 = W4 (128-row tiles), 1 = W8, 2 = PP, 4 = W64 (256-row tiles);
+// -1 for an unknown hint. KV splits live in the free-running kernels only: the 8-wave one stands in
+// for the two long-prompt kernels (within 3-7 % of them unsplit).
+static int prefill_cfg(int max_seqlen_q, int nsplit, int kernel_hint) {
+  int cfg = max_seqlen_q >= 2048 ? 2 : (max_seqlen_q > 1024 ? 1 : 0);
+  switch (kernel_hint & 0xff) {
+    case LV_PREFILL_KERNEL_AUTO: break;
+    case LV_PREFILL_KERNEL_W4: cfg = 0; break;
+    case LV_PREFILL_KERNEL_W8: cfg = 1; break;
+    case LV_PREFILL_KERNEL_PP: cfg = 2; break;
+    case LV_PREFILL_KERNEL_W64: cfg = 4; break;
+    default: return -1;
+  }
+  if (nsplit > 1 && (cfg == 2 || cfg == 4)) cfg = 1;
+  return cfg;
+}
+
+int prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint) {
+  const int cfg = prefill_cfg(max_seqlen_q, num_splits, kernel_hint);
+  return cfg < 0 ? 0 : (cfg == 0 ? 128 : 256);
+}
+
+int prefill_order_columns(int num_kv_heads) {
+  return (num_kv_heads == 1 || num_kv_heads == 2 || num_kv_heads == 4) ? 8 / num_kv_heads : 1;
+}
+
 int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
-  if (static_cast<int64_t>((p.max_seqlen_q + 127) / 128) * p.num_heads * p.batch * p.nsplit > INT32_MAX)
+  if (grid_items(p, 128) * p.num_heads * p.nsplit > INT32_MAX)
     return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
   // cfg 0: 4 waves x 32 rows = 128-row query tiles, two workgroups per CU (short batches keep the
   //        grid wide);  cfg 1: 8 waves x 32 rows = 256-row tiles, half the K/V staging per row;
@@ -1683,20 +1736,12 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   // cfg 4: 4 waves x 64 rows, one wave per SIMD, asm-owned accumulator registers (opt-in).
   // The caller's kernel_hint (LV_PREFILL_KERNEL_*, optionally | LV_PREFILL_STAGE_DMA) overrides
   // the choice by prompt length.
-  const int want = p.kernel_hint & 0xff;
   const int dma = (p.kernel_hint & LV_PREFILL_STAGE_DMA) != 0;
-  int cfg = p.max_seqlen_q >= 2048 ? 2 : (p.max_seqlen_q > 1024 ? 1 : 0);
-  switch (want) {
-    case LV_PREFILL_KERNEL_AUTO: break;
-    case LV_PREFILL_KERNEL_W4: cfg = 0; break;
-    case LV_PREFILL_KERNEL_W8: cfg = 1; break;
-    case LV_PREFILL_KERNEL_PP: cfg = 2; break;
-    case LV_PREFILL_KERNEL_W64: cfg = 4; break;
-    default: return fail(LV_ERR_INVALID_ARGUMENT, "prefill: kernel_hint %d", p.kernel_hint);
-  }
-  // KV splits live in the free-running kernels only: the 8-wave one stands in for the two
-  // long-prompt kernels (within 3-7 % of them unsplit)
-  if (p.nsplit > 1 && (cfg == 2 || cfg == 4)) cfg = 1;
+  const int cfg = prefill_cfg(p.max_seqlen_q, p.nsplit, p.kernel_hint);
+  if (cfg < 0) return fail(LV_ERR_INVALID_ARGUMENT, "prefill: kernel_hint %d", p.kernel_hint);
+  if (p.tile_order && p.order_rows != (cfg == 0 ? 128 : 256))
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order built for %d-row tiles, this launch uses %d-row tiles "
+                "(lv_prefill_tile_rows)", p.order_rows, cfg == 0 ? 128 : 256);
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
   } else if (cfg == 2) {
@@ -1713,7 +1758,7 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   if (p.nsplit > 1) {
     const int64_t pairs = p.total_q * p.num_heads;
     hipLaunchKernelGGL(prefill_merge_kernel, dim3(static_cast<unsigned>((pairs + 7) / 8)), dim3(256), 0, stream,
-                       p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads, p.nsplit, pairs);
+                       p.ws_o, p.ws_ml, p.o, p.o_stride0, p.num_heads, p.nsplit, pairs, p.cu_q, p.batch);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "prefill_merge launch: %s", hipGetErrorString(e));
   }

@@ -251,6 +251,7 @@ class ModelRunner:
     def prepare_prefill(self, seqs: list[Sequence]):
         input_ids, positions, slot_mapping = [], [], []
         cu_q, cu_k = [0], [0]
+        lens_q, lens_k = [], []
         max_q = max_k = 0
         bs = self.block_size
         for seq in seqs:
@@ -259,6 +260,8 @@ class ModelRunner:
             input_ids.extend(seq[cached:])
             positions.extend(range(cached, n))
             lq, lk = n - cached, n
+            lens_q.append(lq)
+            lens_k.append(lk)
             cu_q.append(cu_q[-1] + lq)
             cu_k.append(cu_k[-1] + lk)
             max_q, max_k = max(max_q, lq), max(max_k, lk)
@@ -276,7 +279,14 @@ class ModelRunner:
         cu_q_t = self._to_device(cu_q, torch.int32)
         cu_k_t = self._to_device(cu_k, torch.int32)
         slot_mapping = self._to_device(slot_mapping, torch.int32)
-        set_context(True, cu_q_t, cu_k_t, max_q, max_k, slot_mapping, None, block_tables)
+        # launch order of the query tiles for the prefill kernels: on a tensor-parallel shard with
+        # fewer than 8 kv heads it keeps each sequence's K/V stream on one or two XCDs (None otherwise)
+        tile_order = None
+        if self.on_gpu and max_q > 0:
+            hf = self.config.hf_config
+            tile_order = ops.prefill_tile_order(lens_q, lens_k, hf.num_attention_heads // self.world_size,
+                                                hf.num_key_value_heads // self.world_size, self.device)
+        set_context(True, cu_q_t, cu_k_t, max_q, max_k, slot_mapping, None, block_tables, tile_order=tile_order)
         return input_ids, positions
 
     def prepare_decode(self, seqs: list[Sequence]):

@@ -48,7 +48,7 @@ class Attention(nn.Module):
                 k, v = k_cache, v_cache
             o = ops.prefill_attention(q, k, v, context.cu_seqlens_q, context.cu_seqlens_k,
                                       context.max_seqlen_q, context.max_seqlen_k, self.scale,
-                                      block_table=context.block_tables)
+                                      block_table=context.block_tables, tile_order=context.tile_order)
         else:
             o = ops.decode_attention(q, k_cache, v_cache, context.context_lens,
                                      context.block_tables, self.scale, seq_order=context.seq_order)

@@ -17,6 +17,40 @@ PREFILL_KERNELS = {"auto": 0, "w4": 1, "w8": 2, "pp": 3, "w64": 5, "w4_dma": 1 |
 # Process-wide default for calls that do not name a kernel (the parity tests iterate over the
 # kernels by setting these; "valu" applies where that kernel exists, group sizes 1, 2, 4, 8).
 DEFAULT_KERNEL = {"decode": "auto", "prefill": "auto"}
+STATS = {"tile_order_dropped": 0}
+
+
+def prefill_tile_order(lens_q, lens_k, num_heads: int, num_kv_heads: int, device,
+                       num_splits: int = 0, kernel: Optional[str] = None, force: bool = False):
+    """Launch order of the query tiles for a prefill call on sequences of lens_q new rows over lens_k
+    keys (python ints; the caller of the reference's flash_attn_varlen_func has them when it builds
+    cu_seqlens, lightvllm/engine/model_runner.py:325-328), as a prefill_order.TileOrder on `device`
+    to pass to prefill_attention. None when the library's own mapping serves as well: 8 or more
+    kv heads per rank (one XCD per kv head already; measured equal or 1 % slower with a table).
+    With 1, 2 or 4 kv heads the table keeps each sequence's K/V stream on one or two XCDs
+    (4 x 4096 tokens, 8q/1kv: 0.192 -> 0.147 ms; 16 x 1024, 4q/1kv: 0.039 -> 0.032 ms), and a launch
+    that would put at most one 256-row workgroup on a CU is planned on 128-row tiles instead, so
+    that every CU gets a heavy and a light tile (4 x 4096, 4q/1kv: 0.107 -> 0.099 ms).
+    force: build a table whatever the head count (tests)."""
+    from .prefill_order import build_tile_order, order_columns
+    lens_q, lens_k = [int(x) for x in lens_q], [int(x) for x in lens_k]
+    if not lens_q or max(lens_q) <= 0 or (order_columns(num_kv_heads) == 1 and not force):
+        return None
+    lib = _lib.load()
+    max_q, max_k = max(lens_q), max(lens_k)
+    nsplit = num_splits if num_splits > 0 else lib.lv_prefill_num_splits(len(lens_q), max_q, max_k, num_heads)
+    name = kernel or DEFAULT_KERNEL["prefill"]
+    if name == "auto" and nsplit == 1:
+        wgs256 = sum(-(-lq // 256) for lq in lens_q) * num_heads
+        if 128 < wgs256 <= 256 and lib.lv_prefill_tile_rows(max_q, 1, 0) == 256:
+            name = "w4"
+    rows = lib.lv_prefill_tile_rows(max_q, nsplit, PREFILL_KERNELS[name])
+    order = build_tile_order(lens_q, lens_k, max_q, rows, num_kv_heads)
+    if order is None:
+        return None
+    order.kernel = name if name != (kernel or DEFAULT_KERNEL["prefill"]) else None
+    order.num_splits = nsplit
+    return order.to(device)
 
 
 def _decode_hint(kernel: Optional[str], group: int) -> int:
@@ -74,7 +108,7 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                       max_seqlen_q: int, max_seqlen_k: int, softmax_scale: float,
                       block_table: Optional[torch.Tensor] = None,
                       out: Optional[torch.Tensor] = None, kernel: Optional[str] = None,
-                      num_splits: int = 0) -> torch.Tensor:
+                      num_splits: int = 0, tile_order=None) -> torch.Tensor:
     """Varlen causal attention (bottom-right aligned mask), GQA, optional paged K/V.
 
     q: [total_q, Hq, D]. Packed mode: k/v [total_k, Hkv, D]. Paged mode (block_table given):
@@ -82,6 +116,10 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     kernel: a key of PREFILL_KERNELS to force one kernel (default: DEFAULT_KERNEL["prefill"]).
     num_splits: KV splits per query tile (0 = library heuristic: only for few query rows against
     a long context; 1 = one pass; n = n runs + a merge pass through the per-device workspace).
+    tile_order: optional prefill_order.TileOrder (its table an int32 tensor on q's device): the launch
+    order of the query tiles built from the host's sequence lengths. A performance hint only - it is
+    dropped (counted in STATS) when it was built for another tile height than this launch's kernel
+    uses or for another max_seqlen_q.
     """
     dev = _require_gpu(q, k, v, cu_seqlens_q, cu_seqlens_k)
     total_q, Hq, D = q.shape
@@ -116,13 +154,27 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     lib = _lib.load()
     nsplit = num_splits if num_splits > 0 else lib.lv_prefill_num_splits(B, int(max_seqlen_q), int(max_seqlen_k), Hq)
     ws_ptr, ws_bytes, keep = _workspace(dev, lib.lv_prefill_workspace_bytes(total_q, Hq, D, nsplit))
+    name = kernel or DEFAULT_KERNEL["prefill"]
+    if tile_order is not None and tile_order.kernel and kernel is None and name == "auto":
+        name = tile_order.kernel        # the table was planned on another tile height than the default kernel's
+    hint = PREFILL_KERNELS[name]
+    to_ptr, to_len, to_rows = None, 0, 0
+    if tile_order is not None:
+        if (tile_order.tile_rows == lib.lv_prefill_tile_rows(int(max_seqlen_q), nsplit, hint)
+                and tile_order.max_seqlen_q == int(max_seqlen_q)
+                and tile_order.cols == lib.lv_prefill_order_columns(Hkv)):
+            tab = tile_order.table
+            assert tab.dtype == torch.int32 and tab.is_contiguous() and tab.device == q.device
+            to_ptr, to_len, to_rows = tab.data_ptr(), tab.numel(), tile_order.tile_rows
+        else:
+            STATS["tile_order_dropped"] += 1
     with torch.cuda.device(dev):
         rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                  q.stride(0), k_stride0, v_stride0, out.stride(0),
                                  cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), B,
                                  int(max_seqlen_q), int(max_seqlen_k), bt_ptr, bt_stride, block_size,
                                  Hq, Hkv, D, float(softmax_scale), total_q, ws_ptr, ws_bytes, nsplit,
-                                 PREFILL_KERNELS[kernel or DEFAULT_KERNEL["prefill"]], _stream_ptr(dev))
+                                 to_ptr, to_len, to_rows, hint, _stream_ptr(dev))
     del keep
     _lib.check(rc, "lv_prefill_attn")
     return out

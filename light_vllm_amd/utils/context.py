@@ -2,8 +2,9 @@
 
 Same contract as the reference's lightvllm/utils/context.py:15-75: a module-global dataclass that
 `set_context` replaces wholesale before each forward pass and `reset_context` clears after it.
-Field order and defaults match so positional `set_context(...)` calls behave identically; the one
-extra field, `seq_order`, comes last and defaults to None.
+Field order and defaults match so positional `set_context(...)` calls behave identically; the two
+extra fields, `seq_order` and `tile_order`, come last and default to None (launch-order hints the
+runner builds from the lengths it has on the host; results never depend on them).
 Not thread-safe, by design of the contract (one Python thread per rank process).
 """
 from __future__ import annotations
@@ -25,6 +26,7 @@ class Context:
     context_lens: Optional[torch.Tensor] = None   # int32 [B], decode only
     block_tables: Optional[torch.Tensor] = None   # int32 [B, max_blocks], -1 padded
     seq_order: Optional[torch.Tensor] = None      # int32 [B], decode only: launch order, longest first
+    tile_order: Optional[object] = None           # prefill only: prefill_order.TileOrder (query-tile launch order)
 
 
 _CONTEXT = Context()
@@ -35,10 +37,11 @@ def get_context() -> Context:
 
 
 def set_context(is_prefill, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0, max_seqlen_k=0,
-                slot_mapping=None, context_lens=None, block_tables=None, seq_order=None) -> None:
+                slot_mapping=None, context_lens=None, block_tables=None, seq_order=None,
+                tile_order=None) -> None:
     global _CONTEXT
     _CONTEXT = Context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-                       slot_mapping, context_lens, block_tables, seq_order)
+                       slot_mapping, context_lens, block_tables, seq_order, tile_order)
 
 
 def reset_context() -> None:

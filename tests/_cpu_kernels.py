@@ -15,7 +15,7 @@ def _store(key, value, k_cache, v_cache, slot_mapping):
 
 
 def _prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
-             block_table=None, out=None):
+             block_table=None, out=None, tile_order=None):
     return orc.prefill_ref(q, k, v, cu_seqlens_q, cu_seqlens_k, softmax_scale, block_table).to(q.dtype)
 
 

@@ -20,7 +20,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
-        "lv_prefill_num_splits", "lv_prefill_workspace_bytes",
+        "lv_prefill_num_splits", "lv_prefill_workspace_bytes", "lv_prefill_tile_rows", "lv_prefill_order_columns",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
         "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm"])
 
@@ -58,6 +58,12 @@ def test_host_only_entry_points():
     assert lib.lv_prefill_num_splits(8, 100, 4196, 8) == 8       # 64 workgroups, 66 tiles
     assert lib.lv_prefill_num_splits(8, 100, 4196, 32) == 2      # 256 workgroups
     assert lib.lv_prefill_num_splits(1, 100, 32768, 8) == 32     # 8 workgroups, 512 tiles
+    # query rows per tile of the kernel a launch runs; columns of a tile_order table
+    assert lib.lv_prefill_tile_rows(1024, 1, 0) == 128 and lib.lv_prefill_tile_rows(1025, 1, 0) == 256
+    assert lib.lv_prefill_tile_rows(4096, 1, 0) == 256 and lib.lv_prefill_tile_rows(100, 8, 0) == 128
+    assert lib.lv_prefill_tile_rows(100, 1, 3) == 256 and lib.lv_prefill_tile_rows(4096, 1, 1) == 128
+    assert lib.lv_prefill_tile_rows(100, 1, 77) == 0
+    assert [lib.lv_prefill_order_columns(h) for h in (1, 2, 3, 4, 8, 16)] == [8, 4, 1, 2, 1, 1]
     assert lib.lv_prefill_num_splits(1, 40, 1064, 8) == 2        # 17 tiles: runs of >= 8
     # whole prompts: up to 128 workgroups as above; 129..256 only from 8192 keys
     assert lib.lv_prefill_num_splits(1, 4096, 4096, 4) == 8      # 64 workgroups
@@ -91,10 +97,10 @@ def test_argument_validation_happens_before_any_launch():
     rc = lib.lv_store_kvcache(p16, p16, 512, 1024, p16, p16, p16, 1, 8, 128, 256, None)
     assert rc == -1
     # heads not divisible
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 8, None, 0, 1, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 8, None, 0, 1, None, 0, 0, 0, None)
     assert rc == -1
     # scale must be finite and positive (a zero scale would turn the pre-scaled prefill kernel's constants into NaN)
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 8, None, 0, 1, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 8, None, 0, 1, None, 0, 0, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()
     rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, float("nan"), None, 0, 1, None, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()

@@ -195,3 +195,105 @@ def test_prefill_sequence_without_new_tokens(gpu, num_splits):
     ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"], case["block_table"])
     assert (out[:sum(lens_q)].float().cpu() - ref).abs().max().item() <= TOL
     assert bool((out[sum(lens_q):] == 7.0).all())
+
+
+# ---- host-built launch order of the query tiles: the same bits as the library's own mapping
+def _order_for(gpu, lens_q, lens_k, Hq, Hkv, num_splits=0):
+    from light_vllm_amd import ops
+    return ops.prefill_tile_order(lens_q, lens_k, Hq, Hkv, gpu, num_splits=num_splits, force=True)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (8, 2), (16, 4), (32, 8), (6, 2), (9, 3)])
+def test_prefill_tile_order_same_bits(gpu, Hq, Hkv):
+    """Packed ragged batch incl. an empty sequence: every tile appears once in the table, so the
+    output is the library's own, bit for bit; rows behind the output stay untouched."""
+    from light_vllm_amd import ops
+    lens = [700, 1, 0, 129, 2100, 256, 513]
+    case = make_prefill_case(71, lens, lens, Hq, Hkv)
+    d = to_dev(case, gpu)
+    order = _order_for(gpu, lens, lens, Hq, Hkv)
+    _check(gpu, case)
+    # the plan may name a kernel of its own (128-row tiles for a small grid): compare like with like
+    base = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                                 kernel=order.kernel)
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"])
+    assert (base.float().cpu() - ref).abs().max().item() <= TOL
+    dropped = ops.STATS["tile_order_dropped"]
+    out = torch.full((sum(lens) + 8, Hq, 128), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                          out=out[:sum(lens)], tile_order=order)
+    torch.cuda.synchronize()
+    assert ops.STATS["tile_order_dropped"] == dropped, "the table did not match the launch it was built for"
+    assert torch.equal(out[:sum(lens)].view(torch.int16), base.view(torch.int16))
+    assert bool((out[sum(lens):] == 7.0).all())
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 1), (32, 8)])
+@pytest.mark.parametrize("num_splits", [0, 3])
+def test_prefill_tile_order_prefix_cached_splits(gpu, Hq, Hkv, num_splits):
+    """Paged prefix mode with KV runs: table and split dimension together."""
+    from light_vllm_amd import ops
+    lens_k = [2304 + 40, 4352 + 300, 1024 + 7, 512]
+    cached = [2304, 4352, 1024, 512]
+    lens_q = [k - c for k, c in zip(lens_k, cached)]
+    case = make_prefill_case(72, lens_q, lens_k, Hq, Hkv, paged=True)
+    d = to_dev(case, gpu)
+    order = _order_for(gpu, lens_q, lens_k, Hq, Hkv, num_splits)
+    base = _check(gpu, case, num_splits=num_splits)
+    dropped = ops.STATS["tile_order_dropped"]
+    out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                                block_table=d["block_table"], num_splits=num_splits, tile_order=order)
+    torch.cuda.synchronize()
+    assert ops.STATS["tile_order_dropped"] == dropped
+    assert torch.equal(out.view(torch.int16), base.view(torch.int16))
+
+
+def test_prefill_tile_order_for_other_tile_height_is_rejected_by_the_abi(gpu):
+    """ops drops a table built for another kernel; the C entry point itself refuses it."""
+    from light_vllm_amd import ops, _lib
+    lens = [300, 200]
+    case = make_prefill_case(73, lens, lens, 8, 1)
+    d = to_dev(case, gpu)
+    from light_vllm_amd.prefill_order import build_tile_order
+    hint = ops.PREFILL_KERNELS[ops.DEFAULT_KERNEL["prefill"]]
+    rows = _lib.load().lv_prefill_tile_rows(300, 1, hint)
+    wrong = build_tile_order(lens, lens, 300, 384 - rows, 1).to(gpu)      # 256 <-> 128
+    before = ops.STATS["tile_order_dropped"]
+    out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], 300, 300, d["scale"], tile_order=wrong)
+    torch.cuda.synchronize()
+    assert ops.STATS["tile_order_dropped"] == before + 1
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"])
+    assert (out.float().cpu() - ref).abs().max().item() <= TOL
+    lib = _lib.load()
+    q, k, v = d["q"], d["k"], d["v"]
+    rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
+                             v.stride(0), out.stride(0), d["cu_q"].data_ptr(), d["cu_k"].data_ptr(), 2, 300, 300,
+                             None, 0, 0, 8, 1, 128, float(d["scale"]), q.size(0), None, 0, 1,
+                             wrong.table.data_ptr(), wrong.table.numel(), wrong.tile_rows, hint, None)
+    assert rc == -1 and b"tile_order" in lib.lv_last_error()
+    rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
+                             v.stride(0), out.stride(0), d["cu_q"].data_ptr(), d["cu_k"].data_ptr(), 2, 300, 300,
+                             None, 0, 0, 8, 1, 128, float(d["scale"]), q.size(0), None, 0, 1,
+                             wrong.table.data_ptr(), 7, rows, hint, None)
+    assert rc == -1 and b"tile_order_len" in lib.lv_last_error()
+
+
+def test_prefill_tile_order_planned_on_smaller_tiles(gpu, kernel_config):
+    """A launch of at most one 256-row workgroup per CU is planned on 128-row tiles (the table then
+    names its kernel); the output is still the default launch's."""
+    from light_vllm_amd import ops
+    if kernel_config != "auto":
+        pytest.skip("the plan only overrides the library's own kernel choice")
+    lens = [2100, 2048]            # 9 + 8 tiles of 256 rows x 8 heads = 136 workgroups
+    case = make_prefill_case(74, lens, lens, 8, 2)
+    d = to_dev(case, gpu)
+    order = ops.prefill_tile_order(lens, lens, 8, 2, gpu)
+    assert order is not None and order.kernel == "w4" and order.tile_rows == 128 and order.cols == 4
+    base = _check(gpu, case)
+    out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
+                                tile_order=order)
+    torch.cuda.synchronize()
+    ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"])
+    assert (out.float().cpu() - ref).abs().max().item() <= TOL
+    assert (out.float() - base.float()).abs().max().item() <= 1e-2      # another kernel: same function
+    assert ops.prefill_tile_order(lens, lens, 32, 8, gpu) is None        # 8 kv heads: the library's mapping

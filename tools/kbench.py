@@ -90,8 +90,12 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
                 GBs=round(bytes_ / t / 1e9, 1), pct_peak=round(bytes_ / t / 8e12 * 100, 1))
 
 
-def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=None, num_splits=0):
+def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=None, num_splits=0, order=None):
+    """order: falsy = the library's own tile mapping; else a host-built prefill_order table."""
     total = sum(lens)
+    tile_order = None
+    if order:
+        tile_order = ops.prefill_tile_order(lens, lens, Hq, Hkv, dev, num_splits=num_splits, kernel=kernel, force=True)
 
     def draw(h):
         if data == "uniform":      # uniform in [-2, 2), as tools/prefill_diag.hip
@@ -104,7 +108,8 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=
     out = torch.empty_like(q)
 
     def fn():
-        ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out, kernel=kernel, num_splits=num_splits)
+        ops.prefill_attention(q, k, v, cu, cu, max(lens), max(lens), D ** -0.5, out=out, kernel=kernel, num_splits=num_splits,
+                              tile_order=tile_order)
 
     # matrix-bound kernels run ~19 % slower for the first ~10 ms after an idle GPU (clock ramp):
     # at least 20 untimed launches and 25 ms of them first, so that the timed ones see the clocks a
@@ -122,7 +127,7 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=
     t = timeit(fn, iters=iters, warmup=2)
     flops = sum(4 * Hq * D * (L * L - L * (L - 1) // 2) for L in lens)
     return dict(kind="prefill", data=data, iters=iters, lens=lens if len(lens) <= 8 else f"{len(lens)} seqs", Hq=Hq, Hkv=Hkv,
-                kernel=kernel or ops.DEFAULT_KERNEL["prefill"], runs=num_splits,
+                kernel=kernel or ops.DEFAULT_KERNEL["prefill"], runs=num_splits, order=order,
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
 
 
@@ -247,6 +252,18 @@ def main():
                                           (6, 300, 1024, 8, 1)]:
             for ns in (1, 0, 2, 4, 8):
                 rows.append(prefix_case(B, new, cached, Hq, Hkv, ns))
+    if args.what == "prefill_order":     # library mapping vs host-built tile tables
+        for lens, Hq, Hkv in (([4096] * 4, 8, 1), ([4096] * 4, 4, 1), ([4096] * 2, 8, 2), ([4096] * 4, 16, 4),
+                              ([2048] * 8, 4, 1), ([4096, 3000, 1024, 8264], 8, 1), ([4096, 3000, 1024, 8264], 32, 8),
+                              ([4096] * 4, 32, 8), ([1024] * 16, 4, 1), ([8192] * 2, 8, 1)):
+            for order in (None, "desc"):
+                rows.append(prefill_case(lens, Hq, Hkv, order=order))
+    if args.what == "prefill_order2":    # small grids: kernels x KV runs under a host-built table
+        ops.reserve_decode_workspace(dev, 1 << 30)
+        for lens, Hq, Hkv in (([4096] * 4, 4, 1), ([4096] * 2, 8, 2), ([4096] * 4, 8, 1), ([2048] * 8, 4, 1)):
+            for kernel, ns in (("auto", 0), ("w4", 1), ("w8", 1), ("w8", 2), ("w4", 2), ("pp", 1), ("w64", 1)):
+                for order in (None, "desc"):
+                    rows.append(prefill_case(lens, Hq, Hkv, kernel=kernel, num_splits=ns, order=order))
     if args.what == "prefill1":
         rows.append(prefill_case([4096] * 4, 32, 8))
     if args.what == "decode_c2":         # the bench launch: both kernels, random and all-zero caches, eager and replayed
