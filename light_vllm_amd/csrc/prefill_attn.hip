@@ -72,6 +72,23 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
 #define LV_CLOCK_END
 #endif
 
+// Diagnostic builds (-DLV_TIMELINE, tools/prefill_diag.hip): wall-clock stamps (s_memrealtime, 100 MHz)
+// at the seams of a workgroup's life in prefill_pp_kernel, kept in scalar registers and written once
+// at the end together with the compute unit the workgroup ran on. Nothing in the shipped library.
+#ifdef LV_TIMELINE
+__device__ unsigned long long* g_lv_tl_buf = nullptr;
+#define LV_TL_DECL unsigned long long tl_t[6] = {0, 0, 0, 0, 0, 0};
+#define LV_TL(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+#define LV_TL_FLUSH if (g_lv_tl_buf && threadIdx.x == 0) { \
+  unsigned long long* d = g_lv_tl_buf + static_cast<size_t>(blockIdx.x) * 8; \
+  for (int i = 0; i < 6; ++i) d[i] = tl_t[i]; \
+  d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+#else
+#define LV_TL_DECL
+#define LV_TL(i)
+#define LV_TL_FLUSH
+#endif
+
 // Rescale of the running output is skipped while no row's maximum grows by more than this many
 // powers of two; P then reaches at most 2^kDeferLog2 instead of 1, which fp32 sums and the bf16
 // P operand (same relative precision at any magnitude) absorb.
@@ -695,10 +712,14 @@ void prefill_pp_kernel(const PrefillParams p) {
   constexpr int BM = 32 * NW;
   constexpr int NST = 2;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 32;   // tile rows between them
-  // slot s: K at 2s, V at 2s+1
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kTileBytes];
+  // slot s: K at 2s, V at 2s+1; behind the slots a 64-KiB image of the workgroup's Q tile (8 KiB
+  // per wave, that wave's 32 rows in the K tiles' swizzled row layout)
+  constexpr int kQImg = 4 * kTileBytes;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTileBytes + BM * kHeadDim * 2];
   lds_byte* const lds3 = (lds_byte*)lds;
 
+  LV_TL_DECL
+  LV_TL(0)
   TileWork tw;
   if (!tile_of_block<BM>(p, tw)) return;   // launched with nsplit == 1
   const int kvh = tw.kvh, hq = tw.hq, q0 = tw.q0, b = tw.b;
@@ -732,20 +753,6 @@ void prefill_pp_kernel(const PrefillParams p) {
   const float q_pow = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p.scale_log2e) & 0xff800000u);
   const float c2 = p.scale_log2e / q_pow;
   const float defer_s = kDeferLog2 / c2;
-
-  {
-    const int row_ld = min(my_row, Lq - 1);
-    const uint16_t* qp = p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 + hq * kHeadDim + 8 * h;
-    bf16x8 qtmp[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qtmp[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * q_pow);
-      asm volatile("" ::"v"(qf[s]));   // retire the loads before the tile loop
-    }
-  }
 
   const int last_row = min(q0 + BM - 1, Lq - 1);
   const int max_key = min(last_row + coff, Lk - 1);
@@ -1079,14 +1086,47 @@ void prefill_pp_kernel(const PrefillParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- prologue. The first K/V tiles are requested before Q, and Q comes in whole 256-byte rows
+  // by LDS-DMA (one wave instruction = 4 rows of the wave's own 32, so only the wave's own wait
+  // stands between the copy and its fragment reads): the three latencies overlap, and no lane
+  // gathers 32-byte pieces of 32 different rows.
+  load_rows(0, p.k, k_row_bytes, st_koff, kreg);
+  load_rows(0, p.v, v_row_bytes, st_voff, vreg);
+  {
+    const int lrow = lane >> 4;                                  // row inside a 4-row piece
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      const int r = 4 * pc + lrow;                               // row of the wave's 32
+      const int lchunk = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+      const int row_ld = min(wrow0 + r, Lq - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 +
+                                                          hq * kHeadDim + 8 * lchunk),
+          (__attribute__((address_space(3))) void*)(lds3 + kQImg + wave * 8192 + 1024 * pc), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ntiles > 0) write_rows(0, kreg);
+  __builtin_amdgcn_sched_barrier(0);
+  load_rows(1, p.k, k_row_bytes, st_koff, kreg);
+  {
+    bf16x8 qtmp[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      qtmp[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds3 + kQImg + wave * 8192 + (kbase0 ^ (32 * s)));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * q_pow);
+      asm volatile("" ::"v"(qf[s]));   // retire the reads before the tile loop
+    }
+  }
+  LV_TL(1)
   if (ntiles > 0) {
-    // prologue: K(0) published, K(1) and V(0) in flight (L_K(-1) publishes K(1), L_V(-1) V(0))
-    load_rows(0, p.k, k_row_bytes, st_koff, kreg);
-    load_rows(0, p.v, v_row_bytes, st_voff, vreg);
-    write_rows(0, kreg);
-    load_rows(1, p.k, k_row_bytes, st_koff, kreg);
+    // K(0) published, K(1) and V(0) in flight (L_K(-1) publishes K(1), L_V(-1) V(0))
     __syncthreads();
     if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
+    LV_TL(2)
     LV_CLOCK_BEGIN
     body(-1, IntC<1>{}, IntC<0>{});
     // Every interval also forms the scores of tile i+1; past the last tile they are computed from
@@ -1099,6 +1139,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     if (grp == 0) __syncthreads();
     LV_CLOCK_END
+    LV_TL(3)
   }
   LV_STAMP_FLUSH
 
@@ -1117,6 +1158,12 @@ void prefill_pp_kernel(const PrefillParams p) {
     uint16_t* ob = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim;
     store_row_128(ob, h, my_row < Lq, w);
   }
+  LV_TL(4)
+#ifdef LV_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave's queue
+  LV_TL(5)
+#endif
+  LV_TL_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -194,6 +194,10 @@ def main():
         for lens, Hq, Hkv in (([512] * 32, 32, 8), ([1024] * 16, 32, 8), ([1536] * 10, 32, 8), ([2048] * 8, 32, 8),
                               ([4096] * 4, 32, 8), ([1024] * 16, 16, 8), ([2048] * 8, 4, 1)):
             rows.append(prefill_case(lens, Hq, Hkv))
+    if args.what == "prefill_len":       # 16384 tokens cut into fewer, longer prompts: the cost per query tile beside the cost per key tile
+        for kernel in ("pp", "w8", "w64"):
+            for L in (2048, 4096, 8192, 16384):
+                rows.append(prefill_case([L] * (16384 // L), 32, 8, kernel=kernel))
     if args.what == "prefill_tp8":       # one rank's share of a 4 x 4096 prefill at TP = 8: kernels x KV runs
         ops.reserve_decode_workspace(dev, 1 << 30)
         for Hq, Hkv in ((8, 1), (4, 1)):
