@@ -35,7 +35,7 @@ extern "C" {
 #define LV_ERR_LAUNCH (-3)
 #define LV_ERR_WORKSPACE (-4)
 
-#define LV_ABI_VERSION 8
+#define LV_ABI_VERSION 9
 
 /* kernel_hint of lv_decode_attn: which of the two decode kernels serves the call. */
 #define LV_DECODE_KERNEL_AUTO 0   /* by num_heads / num_kv_heads: vector-ALU for 1-2, matrix-core for 3-8 */
@@ -216,6 +216,10 @@ int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num
 /* Bytes of workspace lv_prefill_attn needs for (total_q, num_heads, num_splits); 0 for <= 1 split. */
 size_t lv_prefill_workspace_bytes(int64_t total_q, int num_heads, int head_dim, int num_splits);
 
+/* Upper bound of lv_prefill_workspace_bytes over every launch of at most max_total_q rows with the
+ * split count lv_prefill_num_splits picks: what a caller reserves once, before it sizes its KV cache. */
+size_t lv_prefill_max_workspace_bytes(int64_t max_total_q, int num_heads, int head_dim);
+
 /*
  * Split count lv_decode_attn will use when called with num_splits == 0, for these static
  * shapes (it never depends on device data, so it is stable under hipGraph replay).
@@ -275,6 +279,41 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
                    int num_heads, int num_kv_heads, int head_dim, float scale,
                    void* workspace, size_t workspace_bytes, int num_splits,
                    const int32_t* seq_order, int kernel_hint, lv_stream_t stream);
+
+/*
+ * lv_decode_attn with a host-built work list, for batches of unequal lengths. The caller of the
+ * reference's flash_attn_with_kvcache (lightvllm/layers/attention.py:172-175) builds context_lens
+ * from len(seq) on the host (lightvllm/engine/model_runner.py:383-418), so it can cut long
+ * sequences into more pieces than short ones and say in which order the pieces start, where
+ * lv_decode_attn must give every sequence the same num_splits (lengths live on the device).
+ * Same function, same results up to the fp32 summation order of the split merge.
+ *
+ *   work_items  device int32 [2 + 2 * num_work_items]: {used, group, then per item: sequence,
+ *               split | (splits of that sequence << 16)}. `used` <= num_work_items items are live.
+ *               Every split 0 .. n_b - 1 of every sequence with context_len > 0 must appear exactly
+ *               once, with the same n_b (<= max_splits) that seq_splits[b] holds. Items run in list
+ *               order (put the longest pieces first) in groups of `group` items x all kv heads.
+ *               An item that does not fit the launch (sequence >= batch, n_b > max_splits,
+ *               split >= n_b) runs nothing; it cannot make the kernels touch memory outside the
+ *               arguments, but its output rows are then not written.
+ *   num_work_items  capacity of the list; it alone sizes the grid (num_work_items x num_kv_heads
+ *               workgroups), so a captured hipGraph replays whatever list the host wrote.
+ *   seq_splits  device int32 [batch]: n_b of every sequence (1 = its one item writes `o` itself; a
+ *               sequence of length 0 needs one item too, which writes its zero row).
+ *   max_splits  split capacity of a workspace row: workspace_bytes >=
+ *               lv_decode_workspace_bytes(batch, num_heads, head_dim, max_splits); no workspace
+ *               needed when it is 1.
+ * light_vllm_amd/decode_plan.py builds the list from python ints.
+ */
+int lv_decode_attn_planned(const void* q, const void* k_cache, const void* v_cache, void* o,
+                           int64_t q_stride0, int64_t o_stride0,
+                           const int32_t* context_lens,
+                           const int32_t* block_table, int block_table_stride,
+                           int batch, int max_blocks_per_seq, int block_size,
+                           int num_heads, int num_kv_heads, int head_dim, float scale,
+                           void* workspace, size_t workspace_bytes, int max_splits,
+                           const int32_t* work_items, int num_work_items,
+                           const int32_t* seq_splits, int kernel_hint, lv_stream_t stream);
 
 /*
  * lv_decode_attn for callers that cannot allocate device memory or carry a workspace (code under

@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvattn.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); must list every symbol include/*.h declares.
 SIGNATURES = {
@@ -45,6 +45,10 @@ SIGNATURES = {
     "lv_decode_attn_static": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p, c_int, c_void_p]),
+    "lv_decode_attn_planned": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_size_t, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "lv_prefill_max_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "lv_comm_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "lv_comm_get_handle": (c_int, [c_void_p, c_void_p]),
     "lv_comm_connect": (c_int, [c_void_p, c_char_p]),

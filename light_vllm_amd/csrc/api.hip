@@ -363,6 +363,16 @@ size_t lv_prefill_workspace_bytes(int64_t total_q, int num_heads, int head_dim, 
   return static_cast<size_t>(total_q) * num_heads * num_splits * (kHeadDim + 2) * sizeof(float);
 }
 
+size_t lv_prefill_max_workspace_bytes(int64_t max_total_q, int num_heads, int head_dim) {
+  if (max_total_q <= 0 || num_heads <= 0 || head_dim != kHeadDim) return 0;
+  // prefill_heuristic_splits cuts only launches of at most 256 workgroups of bm = 128 or 256 rows
+  // (rows x heads <= workgroups x bm) into n <= 512 / workgroups + 1 runs, so
+  // rows x heads x n <= bm x (512 + workgroups) <= 256 x 768; and n <= kMaxPrefillSplits.
+  int64_t units = max_total_q * num_heads * kMaxPrefillSplits;
+  if (units > 256 * 768) units = 256 * 768;
+  return static_cast<size_t>(units) * (kHeadDim + 2) * sizeof(float);
+}
+
 int lv_decode_num_splits(int batch, int num_kv_heads, int max_blocks_per_seq, int block_size) {
   return heuristic_splits(batch, num_kv_heads, max_blocks_per_seq, block_size > 0 ? block_size : 256);
 }
@@ -382,6 +392,7 @@ static int decode_entry(const void* q, const void* k_cache, const void* v_cache,
                         int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
                         int head_dim, float scale, void* workspace, size_t workspace_bytes,
                         bool static_scratch, int num_splits, const int32_t* seq_order,
+                        const int32_t* work_items, int num_work_items, const int32_t* seq_splits,
                         int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_blocks_per_seq < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_splits < 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "decode: negative size");
@@ -413,8 +424,16 @@ static int decode_entry(const void* q, const void* k_cache, const void* v_cache,
     return fail(LV_ERR_UNSUPPORTED, "decode: q/o/caches must be 16-byte aligned with strides %% 8 == 0");
   int nsplit = num_splits == 0 ? heuristic_splits(batch, num_kv_heads, max_blocks_per_seq, block_size) : num_splits;
   if (nsplit > kMaxSplits) return fail(LV_ERR_INVALID_ARGUMENT, "decode: num_splits %d > %d", nsplit, kMaxSplits);
-  if (static_cast<int64_t>(batch) * num_kv_heads * nsplit > INT32_MAX)
+  if (work_items) {
+    // a work list: num_splits is the split capacity of a workspace row, the grid is the list's capacity
+    if (num_splits < 1) return fail(LV_ERR_INVALID_ARGUMENT, "decode: a work list needs max_splits >= 1");
+    if (num_work_items < 1) return fail(LV_ERR_INVALID_ARGUMENT, "decode: a work list needs num_work_items >= 1");
+    if (!seq_splits) return fail(LV_ERR_INVALID_ARGUMENT, "decode: a work list needs seq_splits");
+    if (static_cast<int64_t>(num_work_items) * num_kv_heads > INT32_MAX)
+      return fail(LV_ERR_UNSUPPORTED, "decode: grid too large");
+  } else if (static_cast<int64_t>(batch) * num_kv_heads * nsplit > INT32_MAX) {
     return fail(LV_ERR_UNSUPPORTED, "decode: grid too large");
+  }
   DecodeParams p;
   p.q = static_cast<const uint16_t*>(q);
   p.k_cache = static_cast<const uint16_t*>(k_cache);
@@ -443,6 +462,9 @@ static int decode_entry(const void* q, const void* k_cache, const void* v_cache,
   p.context_lens = context_lens;
   p.block_table = block_table;
   p.seq_order = seq_order;
+  p.work_items = work_items;
+  p.seq_splits = work_items ? seq_splits : nullptr;
+  p.num_work_items = work_items ? num_work_items : 0;
   p.q_stride0 = q_stride0;
   p.o_stride0 = o_stride0;
   p.bt_stride = block_table_stride;
@@ -467,7 +489,7 @@ int lv_decode_attn(const void* q, const void* k_cache, const void* v_cache, void
   return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
                       block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
                       num_kv_heads, head_dim, scale, workspace, workspace_bytes, false, num_splits,
-                      seq_order, kernel_hint, stream);
+                      seq_order, nullptr, 0, nullptr, kernel_hint, stream);
 }
 
 int lv_decode_attn_static(const void* q, const void* k_cache, const void* v_cache, void* o,
@@ -479,7 +501,21 @@ int lv_decode_attn_static(const void* q, const void* k_cache, const void* v_cach
   return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
                       block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
                       num_kv_heads, head_dim, scale, nullptr, 0, true, num_splits, seq_order,
-                      kernel_hint, stream);
+                      nullptr, 0, nullptr, kernel_hint, stream);
+}
+
+int lv_decode_attn_planned(const void* q, const void* k_cache, const void* v_cache, void* o,
+                           int64_t q_stride0, int64_t o_stride0, const int32_t* context_lens,
+                           const int32_t* block_table, int block_table_stride, int batch,
+                           int max_blocks_per_seq, int block_size, int num_heads, int num_kv_heads,
+                           int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                           int max_splits, const int32_t* work_items, int num_work_items,
+                           const int32_t* seq_splits, int kernel_hint, lv_stream_t stream) {
+  if (!work_items) return fail(LV_ERR_INVALID_ARGUMENT, "decode_planned: work_items is null");
+  return decode_entry(q, k_cache, v_cache, o, q_stride0, o_stride0, context_lens, block_table,
+                      block_table_stride, batch, max_blocks_per_seq, block_size, num_heads,
+                      num_kv_heads, head_dim, scale, workspace, workspace_bytes, false, max_splits,
+                      nullptr, work_items, num_work_items, seq_splits, kernel_hint, stream);
 }
 
 }  // extern "C"

@@ -69,22 +69,54 @@ __device__ __forceinline__ void work_item(const DecodeParams& p, int bk, int& b,
   kvh = rem / size;
 }
 
+// What a workgroup serves: split `split` of `nsplit` of sequence b's tokens, kv head kvh.
+// Without a work list every sequence is cut into the launch's p.nsplit splits (split fastest in
+// the workgroup index). With one (lv_decode_attn_planned: the caller knows the lengths and has cut
+// long sequences into more pieces than short ones, pieces in the order they should start) the list
+// is {used items, group size, then per item: sequence, split | splits of that sequence << 16}; the
+// workgroup index walks groups of `group size` items x all kv heads, items fastest. The list lives
+// in device memory, so a captured graph follows whatever the host wrote before the replay; entries
+// past `used`, and entries that do not fit the launch (sequence out of range, more splits than the
+// workspace has room for), run nothing. p.nsplit is then only the split capacity of a workspace row.
+struct DecodeWork { int b, kvh, split, nsplit; };
+__device__ __forceinline__ bool decode_work(const DecodeParams& p, DecodeWork& w) {
+  const int bid = blockIdx.x;
+  if (p.work_items == nullptr) {
+    w.nsplit = p.nsplit;
+    w.split = bid % p.nsplit;
+    work_item(p, bid / p.nsplit, w.b, w.kvh);   // caller-chosen launch order (longest first), if any
+    return static_cast<unsigned>(w.b) < static_cast<unsigned>(p.batch);
+  }
+  const int used = min(p.work_items[0], p.num_work_items);
+  const int gs = max(p.work_items[1], 1);
+  const int per_group = gs * p.num_kv_heads;
+  const int grp = bid / per_group;
+  if (grp * gs >= used) return false;
+  const int rem = bid - grp * per_group;
+  const int size = min(gs, used - grp * gs);                        // the last group may be short
+  w.kvh = rem / size;
+  if (w.kvh >= p.num_kv_heads) return false;
+  const int it = grp * gs + rem % size;
+  w.b = p.work_items[2 + 2 * it];
+  const unsigned code = static_cast<unsigned>(p.work_items[3 + 2 * it]);
+  w.split = static_cast<int>(code & 0xffffu);
+  w.nsplit = static_cast<int>(code >> 16);
+  return static_cast<unsigned>(w.b) < static_cast<unsigned>(p.batch) && w.nsplit >= 1 &&
+         w.nsplit <= p.nsplit && w.split < w.nsplit;
+}
+
 template <int G, int U, bool NT>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) {
   constexpr int TOK = 4 * U;  // tokens per wave chunk
-  const int nsplit = p.nsplit;
   const int Hkv = p.num_kv_heads;
   // Workgroup order: split fastest, then sequence, kv head slowest, so the 8 heads of one token
   // row (8 adjacent 256-byte pieces) are streamed at different times. Measured on this access
   // pattern with no arithmetic at all (tools/hbm_pattern_bw.hip): 7.0 TB/s this way, 6.5 TB/s when
   // the heads of a sequence are read concurrently (kv head fastest, or 8 sequences x 8 rotated
   // heads in adjacent workgroups).
-  const int bid = blockIdx.x;
-  const int split = bid % nsplit;
-  const int bk = bid / nsplit;
-  int b, kvh;
-  work_item(p, bk, b, kvh);   // caller-chosen launch order (longest first), if any
-  if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
+  DecodeWork dw;
+  if (!decode_work(p, dw)) return;
+  const int nsplit = dw.nsplit, split = dw.split, b = dw.b, kvh = dw.kvh;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecodeParams p) 
       const float r = L > 0.f ? val / L : 0.f;
       p.o[static_cast<int64_t>(b) * p.o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
     } else {
-      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * nsplit + split;
+      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * p.nsplit + split;
       p.ws_o[slot * kHeadDim + d] = val;
       if (d == 0) {
         p.ws_ml[slot * 2 + 0] = M;
@@ -335,14 +367,10 @@ __global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams 
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 8192];
   lds_byte_t* const lds3 = (lds_byte_t*)lds;
 
-  const int nsplit = p.nsplit;
   const int Hkv = p.num_kv_heads;
-  const int bid = blockIdx.x;
-  const int split = bid % nsplit;
-  const int bk = bid / nsplit;
-  int b, kvh;
-  work_item(p, bk, b, kvh);   // caller-chosen launch order (longest first), if any
-  if (static_cast<unsigned>(b) >= static_cast<unsigned>(p.batch)) return;
+  DecodeWork dw;
+  if (!decode_work(p, dw)) return;
+  const int nsplit = dw.nsplit, split = dw.split, b = dw.b, kvh = dw.kvh;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma_kernel(const DecodeParams 
       const float r = L > 0.f ? val / L : 0.f;
       p.o[static_cast<int64_t>(b) * p.o_stride0 + hq * kHeadDim + d] = f32_to_bf16_bits(r);
     } else {
-      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * nsplit + split;
+      const int64_t slot = (static_cast<int64_t>(b) * p.num_heads + hq) * p.nsplit + split;
       p.ws_o[slot * kHeadDim + d] = val;
       if (d == 0) {
         p.ws_ml[slot * 2 + 0] = M;
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
                                                            const float* __restrict__ ws_ml,
                                                            uint16_t* __restrict__ o,
                                                            int64_t o_stride0, int num_heads,
-                                                           int nsplit) {
+                                                           int ws_splits, const int32_t* __restrict__ seq_splits) {
   constexpr int LPG = 32 / DS;          // lanes per group
   constexpr int NG = 256 / LPG;         // groups
   constexpr int DIMS = kHeadDim / DS;   // output dims of this workgroup
@@ -561,7 +589,12 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   const int tid = threadIdx.x;
   const int grp = tid / LPG;
   const int ln = tid % LPG;
-  const int64_t base = static_cast<int64_t>(bh) * nsplit;
+  // With per-sequence split counts (a work-list launch) a workspace row still has room for
+  // ws_splits partials, of which this sequence filled the first seq_splits[b]; a sequence served in
+  // one piece was written to `o` by the attention kernel itself.
+  const int nsplit = seq_splits ? min(seq_splits[b], ws_splits) : ws_splits;
+  if (nsplit <= 1 && seq_splits) return;
+  const int64_t base = static_cast<int64_t>(bh) * ws_splits;
 
   // The first kPre partials of this group are requested before the maximum is known: the two
   // load latencies (statistics, partial outputs) then overlap instead of following each other.
@@ -627,16 +660,19 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
   }
 }
 
+static unsigned decode_grid(const DecodeParams& p) {
+  if (p.work_items) return static_cast<unsigned>(p.num_work_items) * p.num_kv_heads;
+  return static_cast<unsigned>(p.batch) * p.num_kv_heads * p.nsplit;
+}
+
 template <int G, int U>
 static void launch_g(const DecodeParams& p, hipStream_t stream) {
-  const unsigned grid = static_cast<unsigned>(p.batch) * p.num_kv_heads * p.nsplit;
-  hipLaunchKernelGGL((decode_attn_kernel<G, U, true>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((decode_attn_kernel<G, U, true>), dim3(decode_grid(p)), dim3(256), 0, stream, p);
 }
 
 template <int G>
 static void launch_mfma(const DecodeParams& p, hipStream_t stream) {
-  const unsigned grid = static_cast<unsigned>(p.batch) * p.num_kv_heads * p.nsplit;
-  hipLaunchKernelGGL((decode_mfma_kernel<G>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((decode_mfma_kernel<G>), dim3(decode_grid(p)), dim3(256), 0, stream, p);
 }
 
 int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
@@ -668,10 +704,10 @@ int launch_decode_attn(const DecodeParams& p, hipStream_t stream) {
     // under graph replay; eight per pair measured 10.2; below 128 splits nothing moves either way.
     if (pairs <= 64 && p.nsplit >= 64)
       hipLaunchKernelGGL(decode_merge_kernel<4>, dim3(pairs * 4), dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o,
-                         p.o_stride0, p.num_heads, p.nsplit);
+                         p.o_stride0, p.num_heads, p.nsplit, p.seq_splits);
     else
       hipLaunchKernelGGL(decode_merge_kernel<1>, dim3(pairs), dim3(256), 0, stream, p.ws_o, p.ws_ml, p.o,
-                         p.o_stride0, p.num_heads, p.nsplit);
+                         p.o_stride0, p.num_heads, p.nsplit, p.seq_splits);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(LV_ERR_LAUNCH, "decode_merge launch: %s", hipGetErrorString(e));
   }

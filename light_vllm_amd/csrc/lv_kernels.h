@@ -15,6 +15,9 @@ struct DecodeParams {
   const int32_t* context_lens;
   const int32_t* block_table;
   const int32_t* seq_order;  // optional launch order of the sequences (nullptr = identity)
+  const int32_t* work_items; // optional work list {used, group size, (sequence, split | splits << 16) ...}
+  const int32_t* seq_splits; // with a work list: splits of every sequence [batch]
+  int num_work_items;        // capacity of the list in items = workgroups per kv head of the launch
   int64_t q_stride0, o_stride0;
   int bt_stride, batch, block_size, num_heads, num_kv_heads, nsplit;
   int kernel_hint;           // LV_DECODE_KERNEL_*

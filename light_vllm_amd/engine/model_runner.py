@@ -14,7 +14,11 @@ MI355X:
   * decode runs from hipGraphs captured per batch-size bucket (:489-548). Padding rows of a bucket
     carry slot -1, which lv_store_kvcache skips, and context_len 0, which lv_decode_attn turns
     into a zero row. (The reference pads with slot 0 and so overwrites cache slot 0 on every
-    padded replay, :448-455.) The split-KV workspace is reserved before capture.
+    padded replay, :448-455.) The split-KV workspace (decode and prefill) is reserved before the KV
+    cache is sized, so nothing allocates once serving has begun;
+  * a decode batch with a few long contexts among short ones is served from a host-built work list
+    (decode_plan.py) that cuts the long ones into pieces: lengths are python ints here (:404-408),
+    where the kernels alone could only give every sequence the same split count.
 """
 from __future__ import annotations
 
@@ -94,6 +98,7 @@ class ModelRunner:
             if self.world_size > 1:
                 dist.barrier()          # every rank has its weights: the first collective starts together
             self.warmup_model()
+            self.reserve_workspace()
             self.allocate_kv_cache()
             if not self.enforce_eager:
                 self.capture_graphs()
@@ -127,7 +132,7 @@ class ModelRunner:
             if self.rank == 0:
                 self.shm.unlink()
         if not self.enforce_eager:
-            del self.graphs, self.graph_pool
+            del self.graphs, self.plan_graphs, self.graph_pool
         if self.on_gpu:
             torch.cuda.synchronize()
         if self.direct_comm is not None:
@@ -186,6 +191,41 @@ class ModelRunner:
         self.run(seqs, True)
         if self.on_gpu:
             torch.cuda.empty_cache()
+
+    def _head_geometry(self):
+        hf = self.config.hf_config
+        hq = hf.num_attention_heads // self.world_size
+        hkv = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        return hq, hkv, head_dim
+
+    def decode_batch_buckets(self):
+        max_bs = min(self.config.max_num_seqs, 512)
+        return [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+
+    def plan_row_splits(self) -> int:
+        """Most pieces a work list cuts one sequence into (= split capacity of a workspace row)."""
+        from ..decode_plan import MIN_PIECE
+        return max(2, min(64, -(-self.config.max_model_len // MIN_PIECE)))
+
+    def reserve_workspace(self) -> None:
+        """One split-KV workspace for everything this runner will launch, reserved BEFORE the KV cache
+        takes the rest of the device: decode at every batch size (the split count the library picks
+        for that shape, and the row capacity of a work list), and prefill at max_num_batched_tokens
+        under the split count the library's heuristic can pick. Nothing grows mid-serving, and a
+        captured graph's workspace address stays valid."""
+        if not self.on_gpu:
+            return
+        cfg = self.config
+        hq, hkv, head_dim = self._head_geometry()
+        max_num_blocks = -(-cfg.max_model_len // self.block_size)
+        sizes = sorted(set(self.decode_batch_buckets() + [cfg.max_num_seqs]))
+        need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks, self.block_size))
+                   for b in sizes)
+        need = max(need, ops.decode_workspace_bytes(max(sizes), hq, head_dim, self.plan_row_splits()))
+        need = max(need, ops._lib.load().lv_prefill_max_workspace_bytes(cfg.max_num_batched_tokens, hq, head_dim))
+        ops.reserve_decode_workspace(self.device, need)
+        self.workspace_bytes = need
 
     def kv_block_bytes(self) -> int:
         hf = self.config.hf_config
@@ -305,12 +345,34 @@ class ModelRunner:
         # does not end on a long straggler; the host already has the lengths. Batches of nearly
         # equal lengths are faster in the kernel's default order (no order passed).
         seq_order = None
-        if max(context_lens_host) - min(context_lens_host) > max(context_lens_host) // 4:
+        plan = self._decode_plan(context_lens_host)
+        if plan is None and max(context_lens_host) - min(context_lens_host) > max(context_lens_host) // 4:
             order = sorted(range(len(seqs)), key=lambda j: -len(seqs[j]))
             seq_order = self._to_device(order, torch.int32)
         set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables,
-                    seq_order=seq_order)
+                    seq_order=seq_order, decode_plan=plan)
         return input_ids, positions
+
+    def _decode_plan(self, lens: list[int]):
+        """A work list for this step's decode attention when the batch holds long outliers (a few
+        contexts far longer than the rest): those are cut into pieces, everything runs longest
+        piece first. None otherwise. For a step that will replay a captured graph the list is built
+        for the graph's bucket: padding rows (length 0) included, capacity and row splits the ones
+        the graph was captured with."""
+        if not self.on_gpu or getattr(self, "config", None) is None:
+            return None
+        from ..decode_plan import build_plan, worth_planning
+        hq, hkv, _ = self._head_geometry()
+        if not worth_planning(lens, hkv, hq // hkv):
+            return None
+        bs = len(lens)
+        if self.enforce_eager or not hasattr(self, "graph_bs") or bs > self.graph_bs[-1]:
+            return build_plan(lens, hkv, hq // hkv, max_splits=self.plan_row_splits()).to(self.device)
+        bucket = next(x for x in self.graph_bs if x >= bs)
+        if bucket not in self.plan_graphs:
+            return None
+        return build_plan(lens + [0] * (bucket - bs), hkv, hq // hkv, max_splits=self.plan_row_splits(),
+                          capacity=bucket + self.plan_extra_items)
 
     def prepare_sample(self, seqs: list[Sequence]) -> torch.Tensor:
         return self._to_device([seq.temperature for seq in seqs], torch.float32)
@@ -336,6 +398,14 @@ class ModelRunner:
         gv["slot_mapping"][:bs] = context.slot_mapping
         gv["context_lens"][:bs] = context.context_lens
         gv["block_tables"][:bs, :context.block_tables.size(1)] = context.block_tables
+        plan = context.decode_plan
+        if plan is not None:
+            # host lists (built for this bucket in prepare_decode) -> the buffers the second graph of
+            # the bucket was captured on
+            gv["plan_items"][:2 + 2 * plan.capacity] = self._to_device(plan.items, torch.int32)
+            gv["plan_seq_splits"][:bucket] = self._to_device(plan.seq_splits, torch.int32)
+            self.plan_graphs[bucket].replay()
+            return head(gv["outputs"][:bs])
         if context.seq_order is not None:
             gv["seq_order"][:bucket] = self._iota[:bucket]  # padding rows keep their own index ...
             gv["seq_order"][:bs] = context.seq_order        # ... behind the real rows, longest first
@@ -344,17 +414,29 @@ class ModelRunner:
         self.graphs[bucket].replay()
         return head(gv["outputs"][:bs])
 
+    def _check_direct_comm(self) -> None:
+        """A direct all-reduce whose peer never arrives gives up inside its kernel (bounded wait) and
+        leaves its output undefined; inside a replayed hipGraph no host call is there to return the
+        error. The failure word is host-mapped, so reading it costs no device sync: every rank reads
+        it around every step and refuses to hand tokens from such a step to the scheduler."""
+        if self.direct_comm is not None and self.direct_comm.failed():
+            raise RuntimeError("a direct all-reduce timed out waiting for a peer: this step's output is undefined "
+                               "(tensor-parallel rank %d)" % self.rank)
+
     def run(self, seqs: list[Sequence], is_prefill: bool, all_greedy: bool = False):
         """all_greedy: rank 0 knows every sequence of the step samples at temperature 0 and says so
         to the other ranks through this argument (sampling parameters do not travel with the step's
         sequences). Under tensor parallelism the ranks then pick the token from per-shard maxima
         instead of gathering [batch, vocab] logits to rank 0 (ParallelLMHead.greedy_tokens): the
         same token, 16 bytes per sequence and rank on the wire instead of 2 * vocab / tp."""
+        self._check_direct_comm()       # ranks that never sync see the steps before this one here
         input_ids, positions = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
         if all_greedy and self.world_size > 1:
             tokens = self.run_model(input_ids, positions, is_prefill, greedy=True)
             reset_context()
-            return tokens.tolist() if self.rank == 0 else None
+            token_ids = tokens.tolist() if self.rank == 0 else None     # rank 0: the step's host sync
+            self._check_direct_comm()
+            return token_ids
         temperatures = self.prepare_sample(seqs) if self.rank == 0 else None
         logits = self.run_model(input_ids, positions, is_prefill)
         token_ids = None
@@ -362,6 +444,7 @@ class ModelRunner:
             all_greedy = all(seq.temperature == 0 for seq in seqs)
             token_ids = self.sampler(logits, temperatures, all_greedy).tolist()
         reset_context()
+        self._check_direct_comm()       # after rank 0's host sync: covers this step's all-reduces
         return token_ids
 
     @torch.inference_mode()
@@ -381,31 +464,44 @@ class ModelRunner:
         outputs = torch.zeros(max_bs, hf.hidden_size, dtype=self.dtype, device=dev)
         self._iota = torch.arange(max_bs, dtype=torch.int32, device=dev)
         seq_order = self._iota.clone()
-        self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+        self.graph_bs = self.decode_batch_buckets()
         self.graphs = {}
         self.graph_pool = None
+        # A second graph per bucket (from 4 sequences up) runs the decode attention from a work list:
+        # the step's list and per-sequence split counts are written into these buffers before the
+        # replay (decode_plan.py). Capacity: one item per row of the bucket plus plan_extra_items
+        # pieces; a workspace row holds plan_row_splits() partials.
+        from ..decode_plan import DecodePlan, natural_plan
+        self.plan_graphs = {}
+        self.plan_extra_items = 512
+        plan_cap = max_bs + self.plan_extra_items
+        plan_items = torch.zeros(2 + 2 * plan_cap, dtype=torch.int32, device=dev)
+        plan_seq_splits = torch.ones(max_bs, dtype=torch.int32, device=dev)
+        row_splits = self.plan_row_splits()
+        self.reserve_workspace()        # a no-op after __init__; covers runners built piecewise (tests)
 
-        hq = hf.num_attention_heads // self.world_size
-        hkv = hf.num_key_value_heads // self.world_size
-        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
-        # every batch size the runner can see, the eager overflow above the largest bucket included,
-        # so the workspace the graphs were captured with is never outgrown
-        need = max(ops.decode_workspace_bytes(b, hq, head_dim, ops.decode_num_splits(b, hkv, max_num_blocks, self.block_size))
-                   for b in self.graph_bs + [cfg.max_num_seqs])
-        ops.reserve_decode_workspace(dev, need)
-
-        for bs in reversed(self.graph_bs):
+        def capture(bs, plan):
             graph = torch.cuda.CUDAGraph()
             set_context(False, slot_mapping=slot_mapping[:bs], context_lens=context_lens[:bs],
-                        block_tables=block_tables[:bs], seq_order=seq_order[:bs])
+                        block_tables=block_tables[:bs], seq_order=seq_order[:bs], decode_plan=plan)
             outputs[:bs] = self.model(input_ids[:bs], positions[:bs])   # warm run outside capture
             with torch.cuda.graph(graph, pool=self.graph_pool):
                 outputs[:bs] = self.model(input_ids[:bs], positions[:bs])
             if self.graph_pool is None:
                 self.graph_pool = graph.pool()
-            self.graphs[bs] = graph
             torch.cuda.synchronize()
             reset_context()
+            return graph
+
+        for bs in reversed(self.graph_bs):
+            self.graphs[bs] = capture(bs, None)
+            if bs >= 4:
+                cap = bs + self.plan_extra_items
+                nat = natural_plan(bs, 1, capacity=cap)      # a valid list for the warm run
+                plan_items[:2 + 2 * cap] = torch.tensor(nat.items, dtype=torch.int32, device=dev)
+                static_plan = DecodePlan(plan_items[:2 + 2 * cap], plan_seq_splits[:bs], cap, row_splits, nat.used, 0)
+                static_plan.workspace_splits = row_splits
+                self.plan_graphs[bs] = capture(bs, static_plan)
         self.graph_vars = dict(input_ids=input_ids, positions=positions, slot_mapping=slot_mapping,
                                context_lens=context_lens, block_tables=block_tables, outputs=outputs,
-                               seq_order=seq_order)
+                               seq_order=seq_order, plan_items=plan_items, plan_seq_splits=plan_seq_splits)

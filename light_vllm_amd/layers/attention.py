@@ -51,5 +51,6 @@ class Attention(nn.Module):
                                       block_table=context.block_tables, tile_order=context.tile_order)
         else:
             o = ops.decode_attention(q, k_cache, v_cache, context.context_lens,
-                                     context.block_tables, self.scale, seq_order=context.seq_order)
+                                     context.block_tables, self.scale, seq_order=context.seq_order,
+                                     plan=context.decode_plan)
         return o.view(-1, self.num_heads * self.head_dim)

@@ -230,7 +230,7 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                      num_splits: int = 0, out: Optional[torch.Tensor] = None,
                      seq_order: Optional[torch.Tensor] = None, kernel: Optional[str] = None,
                      workspace: Optional[torch.Tensor] = None,
-                     static_scratch: bool = False) -> torch.Tensor:
+                     static_scratch: bool = False, plan=None) -> torch.Tensor:
     """One query token per sequence over the paged cache.
 
     q: [B, Hq, D]; caches [num_blocks, block_size, Hkv, D] contiguous; context_lens int32 [B]
@@ -243,6 +243,10 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     workspace: caller-owned uint8 scratch for the split partials (default: the per-device one).
     static_scratch: use lv_decode_attn_static (the library's built-in device array holds the
     partials, nothing is allocated here or there; `out` must then be given).
+    plan: optional decode_plan.DecodePlan on q's device (lv_decode_attn_planned): a work list built
+    from the host's lengths that cuts long sequences into more pieces than short ones; num_splits
+    and seq_order are then ignored. With plan_max_splits (a captured graph's fixed workspace row
+    capacity) attribute absent the plan's own max_splits sizes the workspace.
     """
     dev = _require_gpu(q, k_cache, v_cache, context_lens, block_table)
     B, Hq, D = q.shape
@@ -266,6 +270,29 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     if B == 0:
         return out
     lib = _lib.load()
+    if plan is not None:
+        items, ss = plan.items, plan.seq_splits
+        assert items.dtype == torch.int32 and items.is_contiguous() and items.device == q.device
+        assert ss.dtype == torch.int32 and ss.is_contiguous() and ss.device == q.device
+        assert items.numel() == 2 + 2 * plan.capacity and ss.numel() >= B
+        cap_splits = int(getattr(plan, "workspace_splits", 0) or plan.max_splits)
+        assert cap_splits >= plan.max_splits
+        need = lib.lv_decode_workspace_bytes(B, Hq, D, cap_splits)
+        if workspace is not None:
+            assert workspace.is_cuda and workspace.device == dev and workspace.is_contiguous()
+            ws_ptr, ws_bytes, keep = workspace.data_ptr(), workspace.numel() * workspace.element_size(), workspace
+        else:
+            ws_ptr, ws_bytes, keep = _workspace(dev, need)
+        with torch.cuda.device(dev):
+            rc = lib.lv_decode_attn_planned(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                                            q.stride(0), out.stride(0), context_lens.data_ptr(),
+                                            block_table.data_ptr(), block_table.stride(0), B, max_blocks, block_size,
+                                            Hq, Hkv, D, float(softmax_scale), ws_ptr, ws_bytes, cap_splits,
+                                            items.data_ptr(), plan.capacity, ss.data_ptr(),
+                                            _decode_hint(kernel, Hq // Hkv), _stream_ptr(dev))
+        _lib.check(rc, "lv_decode_attn_planned")
+        del keep
+        return out
     nsplit = num_splits if num_splits > 0 else lib.lv_decode_num_splits(B, Hkv, max_blocks, block_size)
     if static_scratch:
         with torch.cuda.device(dev):

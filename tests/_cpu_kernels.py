@@ -20,7 +20,7 @@ def _prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, so
 
 
 def _decode(q, k_cache, v_cache, context_lens, block_table, softmax_scale, num_splits=0, out=None,
-            seq_order=None):
+            seq_order=None, plan=None):
     return orc.decode_ref(q, k_cache, v_cache, context_lens, block_table, softmax_scale).to(q.dtype)
 
 

@@ -20,6 +20,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_abi_version", "lv_error_string", "lv_last_error", "lv_store_kvcache", "lv_prefill_attn",
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
+        "lv_decode_attn_planned", "lv_prefill_max_workspace_bytes",
         "lv_prefill_num_splits", "lv_prefill_workspace_bytes", "lv_prefill_tile_rows", "lv_prefill_order_columns",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
         "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm"])
@@ -58,6 +59,14 @@ def test_host_only_entry_points():
     assert lib.lv_prefill_num_splits(8, 100, 4196, 8) == 8       # 64 workgroups, 66 tiles
     assert lib.lv_prefill_num_splits(8, 100, 4196, 32) == 2      # 256 workgroups
     assert lib.lv_prefill_num_splits(1, 100, 32768, 8) == 32     # 8 workgroups, 512 tiles
+    # the reservation bound covers every launch the heuristic splits
+    for batch, max_q, max_k, heads in ((8, 100, 4196, 8), (8, 100, 4196, 32), (1, 100, 32768, 8), (1, 4096, 4096, 4),
+                                       (2, 512, 8192, 32), (1, 16384, 16384, 4), (3, 300, 40000, 2), (1, 1, 32768, 1)):
+        n = lib.lv_prefill_num_splits(batch, max_q, max_k, heads)
+        assert lib.lv_prefill_workspace_bytes(batch * max_q, heads, 128, n) <= \
+            lib.lv_prefill_max_workspace_bytes(batch * max_q, heads, 128), (batch, max_q, max_k, heads, n)
+    assert lib.lv_prefill_max_workspace_bytes(16384, 32, 128) == 256 * 768 * 130 * 4
+    assert lib.lv_prefill_max_workspace_bytes(10, 2, 128) == 10 * 2 * 32 * 130 * 4
     # query rows per tile of the kernel a launch runs; columns of a tile_order table
     assert lib.lv_prefill_tile_rows(1024, 1, 0) == 128 and lib.lv_prefill_tile_rows(1025, 1, 0) == 256
     assert lib.lv_prefill_tile_rows(4096, 1, 0) == 256 and lib.lv_prefill_tile_rows(100, 8, 0) == 128

@@ -140,15 +140,32 @@ def _worker(rank, world, port, out_dir, rounds):
                 res["bad"].append(("graph", rep, b.numel()))
     res["failed_after_use"] = c.failed()
     dist.barrier()
-    # a second communicator with a 300 ms timeout: only rank 0 calls, nobody answers
+    # a second communicator with a 300 ms timeout. First a captured all-reduce that every rank
+    # replays (a valid sum), then rank 0 replays the SAME graph alone: nobody answers, the wait
+    # inside the replayed kernel runs out, and no host call is there to notice - the failure word
+    # the host reads after the replay (what ModelRunner.run checks after every step) is the report.
     c2 = lvcomm.create_for_group(dev, timeout_ms=300, self_test=False)   # late peers must not trip the set-up check
+    z = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+    dist.barrier()
+    c2.all_reduce(z)                     # warm run, every rank
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        c2.all_reduce(z)
+    z.fill_(1.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g2.replay()
+    torch.cuda.synchronize()
+    res["joint_replay_ok"] = bool((z == world).all()) and not c2.failed()
+    dist.barrier()
     if rank == 0:
-        z = torch.ones(4096, dtype=torch.bfloat16, device=dev)
         t0 = torch.cuda.Event(enable_timing=True)
         t1 = torch.cuda.Event(enable_timing=True)
         t0.record()
-        c2.all_reduce(z)
+        g2.replay()                      # returns without error: the launch is already recorded
         t1.record()
+        res["dead_before_sync_is_bool"] = isinstance(c2.failed(), bool)   # readable without a device sync
         torch.cuda.synchronize()
         res["timeout_ms"] = t0.elapsed_time(t1)
         res["dead"] = c2.failed()
@@ -184,6 +201,7 @@ def test_direct_all_reduce_shared_gpu(gpu, tmp_path, world):
         assert not res["bad"], f"rank {r}: {res['bad'][:5]}"
         assert res["calls"] == rounds * 2 * len(SIZES)
         assert res["failed_after_use"] is False
+        assert res["joint_replay_ok"] is True
         assert res["fused_cases"] >= (3 if world == 8 else 6)
         if r == 0:
             print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms; [32, 4096] all-reduce + add + RMSNorm "

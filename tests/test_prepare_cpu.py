@@ -143,3 +143,36 @@ def test_positions_beyond_the_rotary_table_are_refused():
     finally:
         Sequence.block_size = 256
         reset_context()
+
+
+def test_run_refuses_tokens_after_a_failed_direct_all_reduce():
+    """A direct all-reduce that gave up inside a replayed graph leaves no host error behind; the
+    runner reads the communicator's failure word around every step and raises instead of handing
+    tokens of such a step to the scheduler."""
+    import pytest
+
+    class _Comm:
+        def __init__(self):
+            self.dead = False
+
+        def failed(self):
+            return self.dead
+
+    r = _runner(256)
+    r.world_size, r.rank = 2, 0
+    r.direct_comm = _Comm()
+    calls = []
+    r.prepare_decode = lambda seqs: (torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64))
+    r.prepare_sample = lambda seqs: torch.zeros(1)
+
+    def run_model(input_ids, positions, is_prefill, greedy=False):
+        calls.append(greedy)
+        r.direct_comm.dead = len(calls) == 2        # the second step's all-reduce times out
+        return torch.tensor([3])
+    r.run_model = run_model
+    assert r.run([object()], False, all_greedy=True) == [3]
+    with pytest.raises(RuntimeError, match="direct all-reduce timed out"):
+        r.run([object()], False, all_greedy=True)
+    with pytest.raises(RuntimeError, match="direct all-reduce timed out"):      # and every step after it, before any work
+        r.run([object()], False, all_greedy=True)
+    assert len(calls) == 2

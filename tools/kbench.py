@@ -50,9 +50,13 @@ def timeit_graph(fn, iters=20, warmup=3, replays=5):
     return e0.elapsed_time(e1) / (iters * replays) * 1e-3
 
 
-def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False, graph=False, data="normal"):
-    bps = (ctx + BLOCK - 1) // BLOCK
-    nblk = B * bps
+def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False, graph=False, data="normal",
+                plan=None, outliers=()):
+    """outliers: lengths that replace the first sequences' (a few long contexts in a batch of short ones).
+    plan: None, or keyword arguments of decode_plan.build_plan (a host-built work list: long
+    sequences cut into more pieces than short ones)."""
+    bps = (max([ctx, *outliers]) + BLOCK - 1) // BLOCK
+    nblk = B * bps if not outliers else B * ((ctx + BLOCK - 1) // BLOCK) + len(outliers) * bps
     # several distinct caches so the working set exceeds the 256 MiB Infinity Cache
     per_layer = 2 * nblk * BLOCK * Hkv * D * 2
     layers = max(layers, min(64, (1 << 30) // max(per_layer, 1) + 1))
@@ -62,21 +66,39 @@ def decode_case(B, ctx, Hq, Hkv, nsplit=0, layers=4, ragged=False, ordered=False
     else:                       # "zeros": the same bytes moved, no switching in the arithmetic
         kv.zero_()
     q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
-    bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
+    if outliers:       # short sequences own ceil(ctx / block) blocks, the long ones a full row
+        perm = torch.randperm(nblk).to(torch.int32)
+        bt_h = torch.zeros(B, bps, dtype=torch.int32)
+        short = (ctx + BLOCK - 1) // BLOCK
+        pos = 0
+        for i in range(B):
+            n = bps if i < len(outliers) else short
+            bt_h[i, :n] = perm[pos:pos + n]
+            pos += n
+        bt = bt_h.to(dev)
+    else:
+        bt = torch.randperm(nblk).to(torch.int32).view(B, bps).to(dev)
     if ragged:
         lens = torch.randint(1, ctx + 1, (B,), dtype=torch.int32, generator=torch.Generator().manual_seed(0))
     else:
         lens = torch.full((B,), ctx, dtype=torch.int32)
+    for i, n in enumerate(outliers):
+        lens[i] = n
     ctx_t = lens.to(dev)
     out = torch.empty_like(q)
     # launch order: longest first, as ModelRunner.prepare_decode passes it
     order = torch.argsort(lens, descending=True, stable=True).to(torch.int32).to(dev) if ordered else None
+    dplan = None
+    if plan is not None:
+        from light_vllm_amd.decode_plan import build_plan
+        dplan = build_plan(lens.tolist(), Hkv, Hq // Hkv, **plan).to(dev)
     state = {"i": 0}
 
     def fn():
         l = state["i"] % layers
         state["i"] += 1
-        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out, seq_order=order)
+        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt, D ** -0.5, num_splits=nsplit, out=out, seq_order=order,
+                             plan=dplan)
 
     if graph:
         ops.reserve_decode_workspace(dev, 256 << 20)
@@ -303,6 +325,24 @@ def main():
         for (Hq, Hkv) in [(32, 8), (16, 8), (64, 8)]:
             for ctx in (1024, 4096):
                 rows.append(decode_case(256, ctx, Hq, Hkv, nsplit=1, ragged=True, ordered=True, graph=True))
+    if args.what == "decode_plan":       # ragged batches: longest-first order against host-built work lists
+        for (Hq, Hkv) in [(32, 8), (16, 8), (64, 8)]:
+            for ctx in (1024, 4096):
+                rows.append(decode_case(256, ctx, Hq, Hkv, nsplit=1, ragged=True, ordered=True, graph=True))
+                for kw in (dict(piece_tokens=256), dict(piece_tokens=384), dict(piece_tokens=512), dict(piece_tokens=1024), dict()):
+                    r = decode_case(256, ctx, Hq, Hkv, ragged=True, graph=True, plan=kw)
+                    r["plan"] = kw or "auto"
+                    rows.append(r)
+    if args.what == "decode_outliers":   # a few long contexts among short ones: one split count for all against a work list
+        for (Hq, Hkv) in [(32, 8), (16, 8)]:
+            for outl in ((16384,) * 4, (32768,), (8192,) * 8):
+                for ns in (1, 0):
+                    rows.append(decode_case(256, 1024, Hq, Hkv, nsplit=ns, ragged=True, ordered=True, graph=True, outliers=outl))
+                for kw in (dict(piece_tokens=512), dict(piece_tokens=1024), dict(piece_tokens=2048), dict()):
+                    r = decode_case(256, 1024, Hq, Hkv, ragged=True, graph=True, plan=kw, outliers=outl)
+                    r["plan"] = kw or "auto"
+                    rows.append(r)
+                rows[-1]["outliers"] = list(outl)
     if args.what == "decode_ragged":
         for (Hq, Hkv) in [(32, 8), (16, 8)]:
             for ns in (1, 2, 4, 8):
