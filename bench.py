@@ -22,10 +22,15 @@ N > 1   BASELINE.json configs[3]: Qwen3-8B under tensor parallelism TP = N. The 
 step time. Inputs are resident in HBM before the timed region.
 
 Auxiliary records on the same JSON line (never part of `value`): `cpu_baseline` (N=1: the CPU oracle
-on the host cores), `prefill` (the prefill kernel on the 4 x 4096 configuration), `config4_tp1`
+on the host cores), `prefill` (the prefill kernel on the 4 x 4096 configuration), `variants` (N=1: the
+other launches the reference's call sites produce - ragged and outlier decode batches, a 32k-context
+8q/1kv decode, varlen / prefix-cached / 8q/1kv prefill, the store at 16384 tokens), `config4_tp1`
 (N=1: the N>1 step at TP=1, the base of the strong-scaling curve), `collectives` (N>1: all-reduce
 latencies, direct path and RCCL) and `e2e` (the engine's tok/s at TP = N in child processes; a
-failure there sets `e2e_failed`). `--no-aux` skips them.
+failure there sets `e2e_failed`). `--no-aux` skips them, `--aux a,b` picks some.
+At every N the line also carries `scale_value` / `scale_ms_per_step`: BASELINE config 4 at TP = N
+(N = 1: the `config4_tp1` leg), one workload whose numbers are comparable across N, with
+`scale_base_ms_per_step` (TP = 1, measured in the same run) and `scale_efficiency` against it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
@@ -126,11 +131,13 @@ class DecodeWorkload:
         for _ in range(steps):
             self.step(events)
         torch.cuda.synchronize()
-        avg_s = sum(a.elapsed_time(b) for a, b in events) / len(events) / 1e3
+        times = sorted(a.elapsed_time(b) for a, b in events)
+        avg_s = sum(times) / len(times) / 1e3
         achieved = self.decode_bytes / avg_s / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": self.decode_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                "median_launch_us": round(times[len(times) // 2] * 1e3, 2), "max_launch_us": round(times[-1] * 1e3, 2),
                 "launches_timed": len(events),
                 "shape": f"B={self.B} ctx={self.ctx} {self.Hq}q/{self.Hkv}kv x {self.layers} layers, splits {self.nsplit}"}
 
@@ -139,24 +146,57 @@ class DecodeWorkload:
         torch.cuda.empty_cache()
 
 
-def recorded_traffic():
-    """HBM bytes per launch of the config-2 decode kernel from the PMC passes of tools/pmc_decode.sh
+def _sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def recorded_traffic(kernel="decode_attn_kernel<2", launch_bytes=None):
+    """HBM bytes per launch of a decode kernel from the PMC passes of tools/pmc_decode.sh
     (profiles/decode_traffic.json). A recording, not a measurement of this run: returned only while
-    the kernel source it was taken on is the one in the tree."""
+    the kernel source it was taken on is the one in the tree. launch_bytes: the algorithmic bytes of
+    the launch in question; the recording of the same kernel whose algorithmic bytes match is used."""
     path = os.path.join(ROOT, "profiles", "decode_traffic.json")
     src = os.path.join(ROOT, "light_vllm_amd", "csrc", "decode_attn.hip")
     try:
         rec = json.load(open(path))
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        sha = _sha16(src)
     except (OSError, ValueError):
         return None, {"kind": "none"}
     source = {"kind": "recorded PMC passes (FETCH_SIZE, WRITE_SIZE), not collected in this run",
-              "file": "profiles/decode_traffic.json", "kernel": rec.get("kernel"),
+              "file": "profiles/decode_traffic.json",
               "recorded_on_kernel_source": rec.get("kernel_source_sha16"), "current_kernel_source": sha}
     if rec.get("kernel_source_sha16") != sha:
         source["kind"] = "stale: recorded on another version of decode_attn.hip, dropped"
         return None, source
-    return rec.get("hbm_bytes_per_launch"), source
+    for name, k in rec.get("kernels", {}).items():
+        if kernel in name and (launch_bytes is None or k.get("algorithmic_bytes_per_launch") == launch_bytes):
+            source["kernel"] = name
+            return k.get("hbm_bytes_per_launch"), source
+    source["kind"] = "no recording of this kernel on this launch"
+    return None, source
+
+
+def recorded_prefill_counters():
+    """Matrix-pipe utilisation of the prefill kernel from rocprofv3 counters (tools/pmc_prefill.sh +
+    tools/pmc_prefill_summary.py on the 4 x 4096, 32q/8kv launch): a recording, shown only while
+    prefill_attn.hip is the source it was taken on."""
+    path = os.path.join(ROOT, "profiles", "prefill_counters.json")
+    src = os.path.join(ROOT, "light_vllm_amd", "csrc", "prefill_attn.hip")
+    try:
+        rec = json.load(open(path))
+        sha = _sha16(src)
+    except (OSError, ValueError):
+        return None
+    out = {"kind": "recorded rocprofv3 --pmc passes, not collected in this run", "file": "profiles/prefill_counters.json",
+           "recorded_on_kernel_source": rec.get("kernel_source_sha16"), "current_kernel_source": sha}
+    if rec.get("kernel_source_sha16") != sha:
+        out["kind"] = "stale: recorded on another version of prefill_attn.hip, dropped"
+        return out
+    for key in ("kernel", "mfma_pipe_busy_fraction", "mfma_flops_over_algorithmic", "l2_hit_rate",
+                "lds_instructions_per_wave_tile", "mfma_instructions_per_wave_tile", "kernel_shader_cycles"):
+        if key in rec:
+            out[key] = rec[key]
+    return out
 
 
 def cpu_model():
@@ -245,6 +285,159 @@ def prefill_leg(ops, dev, n, iters=50, warmup=20):
             "launches": iters, "untimed_launches": warmup, "ms": round(ms, 4),
             "tflops": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "bound": "mfma", "flops_per_launch": flops}
+
+
+def _event_time(fn, iters, warmup=2):
+    """Mean seconds per call of fn, events on the launch stream."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def ragged_decode_leg(ops, dev, Hq, Hkv, lens, how, layers=6, reps=3):
+    """One paged-decode launch per layer cache on a batch of unequal lengths (python ints), blocks
+    handed out as the block manager would (ceil(len / 256) per sequence, random physical order).
+    how: "ordered" = lv_decode_attn with the longest-first launch order ModelRunner.prepare_decode
+    passes, "planned" = lv_decode_attn_planned on the work list decode_plan.build_plan cuts."""
+    from light_vllm_amd.decode_plan import build_plan
+    B = len(lens)
+    need = [-(-n // BLOCK) for n in lens]
+    nblk, width = sum(need), max(need)
+    perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(7)).to(torch.int32)
+    bt = torch.zeros(B, width, dtype=torch.int32)
+    pos = 0
+    for i, n in enumerate(need):
+        bt[i, :n] = perm[pos:pos + n]
+        pos += n
+    kv = torch.empty(layers, 2, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev).normal_()
+    q = torch.randn(B, Hq, D, device=dev).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    ctx_t, bt_d = torch.tensor(lens, dtype=torch.int32, device=dev), bt.to(dev)
+    order = plan = None
+    if how == "ordered":
+        order = torch.tensor(sorted(range(B), key=lambda j: -lens[j]), dtype=torch.int32, device=dev)
+    else:
+        plan = build_plan(lens, Hkv, Hq // Hkv).to(dev)
+    state = {"i": 0}
+
+    def fn():
+        l = state["i"] % layers
+        state["i"] += 1
+        ops.decode_attention(q, kv[l, 0], kv[l, 1], ctx_t, bt_d, D ** -0.5, num_splits=1 if how == "ordered" else 0,
+                             out=out, seq_order=order, plan=plan)
+    torch.cuda.synchronize()
+    time.sleep(SETTLE_S)
+    t = _event_time(fn, layers * reps, warmup=layers)
+    nbytes = sum(lens) * Hkv * D * 4 + 2 * B * Hq * D * 2 + 4 * B + 4 * nblk
+    rec = {"how": how, "heads": f"{Hq}q/{Hkv}kv", "batch": B, "tokens": sum(lens), "longest": max(lens),
+           "bytes_per_launch": nbytes, "avg_launch_us": round(t * 1e6, 2), "achieved": round(nbytes / t / 1e9, 1),
+           "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm"}
+    if plan is not None:
+        rec["pieces"], rec["piece_tokens"], rec["most_pieces_per_sequence"] = plan.used, plan.piece_tokens, plan.max_splits
+    del kv
+    torch.cuda.empty_cache()
+    return rec
+
+
+def prefill_variant_leg(ops, dev, lens, Hq, Hkv, cached=0, iters=30, warmup=20):
+    """Prefill attention on prompts of `lens` tokens whose first `cached` tokens each are already in
+    the paged cache (0: packed K/V, no block table), with the query-tile launch order the runner
+    builds from the lengths (ops.prefill_tile_order; None for 8 kv heads)."""
+    lens_q = [n - cached for n in lens]
+    tq = sum(lens_q)
+    q = torch.randn(tq, Hq, D, device=dev).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    cu_q = torch.tensor([0] + torch.tensor(lens_q).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+    cu_k = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+    order = ops.prefill_tile_order(lens_q, lens, Hq, Hkv, dev)
+    if cached:
+        need = [-(-n // BLOCK) for n in lens]
+        nblk = sum(need)
+        kc = torch.randn(nblk, BLOCK, Hkv, D, device=dev).to(torch.bfloat16)
+        vc = torch.randn(nblk, BLOCK, Hkv, D, device=dev).to(torch.bfloat16)
+        perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(11)).to(torch.int32)
+        bt = torch.full((len(lens), max(need)), -1, dtype=torch.int32)
+        pos = 0
+        for i, n in enumerate(need):
+            bt[i, :n] = perm[pos:pos + n]
+            pos += n
+        bt = bt.to(dev)
+        fn = lambda: ops.prefill_attention(q, kc, vc, cu_q, cu_k, max(lens_q), max(lens), D ** -0.5,   # noqa: E731
+                                           block_table=bt, out=out, tile_order=order)
+    else:
+        k = torch.randn(tq, Hkv, D, device=dev).to(torch.bfloat16)
+        v = torch.randn(tq, Hkv, D, device=dev).to(torch.bfloat16)
+        fn = lambda: ops.prefill_attention(q, k, v, cu_q, cu_k, max(lens_q), max(lens), D ** -0.5,     # noqa: E731
+                                           out=out, tile_order=order)
+    t = _event_time(fn, iters, warmup)
+    flops = sum(4 * Hq * D * (lq * lk - lq * (lq - 1) // 2) for lq, lk in zip(lens_q, lens))
+    return {"prompts": lens, "cached_tokens_each": cached, "heads": f"{Hq}q/{Hkv}kv", "ms": round(t * 1e3, 4),
+            "tflops": round(flops / t / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "frac": round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "bound": "mfma", "flops_per_launch": flops, "tile_order": order is not None}
+
+
+def store_leg(ops, dev, N=16384, Hq=32, Hkv=8, caches=4):
+    """lv_store_kvcache at a prefill's size: N rows into random distinct slots, V a strided view into
+    the fused qkv activation as the model hands it over."""
+    qkv = torch.randn(N, (Hq + 2 * Hkv) * D, device=dev).to(torch.bfloat16)
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].contiguous().view(N, Hkv, D)
+    v = qkv[:, (Hq + Hkv) * D:].view(N, Hkv, D)
+    nblk = 2 * N // BLOCK
+    kv = torch.zeros(caches, 2, nblk, BLOCK, Hkv, D, dtype=torch.bfloat16, device=dev)
+    slots = torch.randperm(nblk * BLOCK, device=dev)[:N].to(torch.int32)
+    state = {"i": 0}
+
+    def fn():
+        c = state["i"] % caches
+        state["i"] += 1
+        ops.store_kvcache(k, v, kv[c, 0], kv[c, 1], slots)
+    t = _event_time(fn, 40, warmup=8)
+    nbytes = store_bytes(N, Hkv)
+    return {"tokens": N, "heads_kv": Hkv, "avg_launch_us": round(t * 1e6, 2), "bytes_per_launch": nbytes,
+            "achieved": round(nbytes / t / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4), "bound": "hbm"}
+
+
+def variants_leg(ops, dev, sync_all):
+    """The other launches the reference's two attention call sites and its store produce
+    (lightvllm/layers/attention.py:104-108, 159-165, 172-175; engine/model_runner.py:369-370 for the
+    prefix-cached mode), each with its own roofline fraction. Every entry stands alone: a failure
+    is recorded in place."""
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as exc:   # noqa: BLE001 - reported, never fatal for the headline number
+            out[name] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
+
+    ragged = torch.randint(1, 1025, (256,), generator=torch.Generator().manual_seed(0)).tolist()
+    leg("decode_ragged_16q8kv", lambda: ragged_decode_leg(ops, dev, 16, 8, ragged, "ordered"))
+    leg("decode_ragged_32q8kv", lambda: ragged_decode_leg(ops, dev, 32, 8, ragged, "ordered"))
+    outl = [16384] * 4 + ragged[4:]
+    leg("decode_outliers_32q8kv_one_split_count", lambda: ragged_decode_leg(ops, dev, 32, 8, outl, "ordered"))
+    leg("decode_outliers_32q8kv_work_list", lambda: ragged_decode_leg(ops, dev, 32, 8, outl, "planned"))
+
+    def c5_decode():
+        w = DecodeWorkload(ops, dev, 4, 8, 1, 64, 32768, seed=77)
+        w.step()
+        r = w.roofline(5, "decode_mfma_kernel<8>")
+        w.free()
+        return r
+    leg("decode_c5_8q1kv_b64_ctx32k", c5_decode)
+    leg("prefill_varlen", lambda: prefill_variant_leg(ops, dev, [4096, 3000, 1024, 8264], 32, 8))
+    leg("prefill_prefix_1024_cached", lambda: prefill_variant_leg(ops, dev, [4096] * 4, 32, 8, cached=1024))
+    leg("prefill_c5_8q1kv", lambda: prefill_variant_leg(ops, dev, [4096] * 4, 8, 1))
+    leg("prefill_c5_8q1kv_prefix_1024_cached", lambda: prefill_variant_leg(ops, dev, [4096] * 4, 8, 1, cached=1024))
+    leg("store_16384_tokens", lambda: store_leg(ops, dev))
+    return out
 
 
 def sustained_mfma_peak():
@@ -386,11 +579,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs")
+    ap.add_argument("--aux", default="prefill,variants,config4,collectives,e2e",
+                    help="comma list of auxiliary legs to run (prefill, variants, config4, collectives, e2e)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE GPU: every rank on cuda:0, gloo group, 4 layers, batch 8 "
                          "(proves launcher, rendezvous, graph and JSON path; not a measurement)")
     args = ap.parse_args()
 
+    aux = set() if args.no_aux else {a for a in args.aux.split(",") if a}
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -437,7 +633,7 @@ def main():
         elapsed, _, _ = run_steps(w.step, args.steps, args.warmup, sync_all, use_graph=False)
         value = w.step_bytes * args.steps / elapsed / 1e9
         roof = w.roofline(args.steps, "decode_attn_kernel<2,8>")
-        roof["traffic"], roof["traffic_source"] = recorded_traffic()
+        roof["traffic"], roof["traffic_source"] = recorded_traffic("decode_attn_kernel<2", w.decode_bytes)
         result.update({
             "value": round(value, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": "weak",
             "config": {"workload": f"BASELINE config 2: {c['name']} shapes TP=1: {c['layers']} layers x (store_kvcache + "
@@ -457,6 +653,7 @@ def main():
         r8["step_GBs"] = round(w8.step_bytes * max(args.steps // 2, 2) / el8 / 1e9, 2)
         r8["workload"] = (f"{c8['name']} shapes TP=1: {c8['layers']} layers x (store_kvcache + paged decode), batch "
                           f"{c8['batch']}, ctx {c8['ctx']}, heads {c8['hq']}q/{c8['hkv']}kv")
+        r8["traffic"], r8["traffic_source"] = recorded_traffic("decode_mfma_kernel<4", w8.decode_bytes)
         result["roofline_8b"] = r8
         w8.free()
     else:
@@ -520,29 +717,55 @@ def main():
         w.free()
 
     t_aux = time.perf_counter()
-    if rank == 0 and not args.no_aux:
+    if rank == 0 and "prefill" in aux:
         try:
             result["prefill"] = prefill_leg(ops, dev, n)
             burn = sustained_mfma_peak()
             if burn:
                 result["prefill"]["sustained_mfma"] = burn
                 result["prefill"]["frac_of_sustained"] = round(result["prefill"]["tflops"] / burn["tflops"], 4)
+            if n == 1:
+                rp = recorded_prefill_counters()
+                if rp:
+                    result["prefill"]["rocprof"] = rp
         except Exception as exc:   # reported, never fatal for the headline number
             result["prefill"] = {"error": repr(exc)[:300]}
-    if n == 1 and not args.no_aux:
+    if n == 1 and "variants" in aux:
+        result["variants"] = variants_leg(ops, dev, sync_all)
+    scale_base = None
+    if "config4" in aux and (n == 1 or rank == 0):
         # the multi-GPU step at TP=1 (no all-reduce): the base of the strong-scaling curve
+        # (a rehearsal keeps its reduced size: 4 layers, batch 8)
         try:
-            w4, _ = tp_step_setup(ops, dev, 1, 0, C4, C4["layers"], C4["batch"])
-            el4, graphed, note = run_steps(w4.step, 5, 2, sync_all, use_graph=True)
+            l4, b4 = (4, 8) if args.rehearse else (C4["layers"], C4["batch"])
+            w4, _ = tp_step_setup(ops, dev, 1, 0, C4, l4, b4)
+            el4, graphed, note = run_steps(w4.step, 5, 2, lambda: torch.cuda.synchronize(), use_graph=True)
             r4 = w4.roofline(1, "decode_mfma_kernel<4>")
-            result["config4_tp1"] = {"workload": f"BASELINE config 4 at TP=1: {C4['layers']} layers x (store_kvcache + paged "
-                                                 f"decode), batch {C4['batch']}, ctx {C4['ctx']}, heads {C4['hq']}q/{C4['hkv']}kv",
+            r4["traffic"], r4["traffic_source"] = recorded_traffic("decode_mfma_kernel<4", w4.decode_bytes)
+            result["config4_tp1"] = {"workload": f"BASELINE config 4 at TP=1: {l4} layers x (store_kvcache + paged "
+                                                 f"decode), batch {b4}, ctx {C4['ctx']}, heads {C4['hq']}q/{C4['hkv']}kv",
                                      "value": round(w4.step_bytes * 5 / el4 / 1e9, 2), "unit": "GB/s",
                                      "ms_per_step": round(el4 / 5 * 1e3, 4), "hipgraph": graphed, "roofline": r4}
+            scale_base = result["config4_tp1"]
             w4.free()
         except Exception as exc:
             result["config4_tp1"] = {"error": repr(exc)[:300]}
-    if n > 1 and not args.no_aux:
+    if n > 1:
+        sync_all()      # the other ranks wait here (process-group barrier) while rank 0 measures the TP = 1 base
+    # One workload whose numbers are comparable at every N: BASELINE config 4 (global batch 32 at 32k
+    # context) at TP = N. N = 1: the leg above; N > 1: the headline itself, beside the TP = 1 step
+    # measured by rank 0 of this same run.
+    if n == 1 and scale_base is not None:
+        result.update(scale_value=scale_base["value"], scale_ms_per_step=scale_base["ms_per_step"])
+    elif n > 1:
+        result.update(scale_value=result["value"], scale_ms_per_step=result["ms_per_step"])
+    if "scale_value" in result:
+        result["scale_workload"] = (f"BASELINE config 4: Qwen3-8B shapes, global batch {8 if args.rehearse else C4['batch']}, "
+                                    f"ctx {C4['ctx']}, TP={n}, hipGraph replay" + (" (rehearsal size)" if args.rehearse else ""))
+        if scale_base is not None:
+            result["scale_base_ms_per_step"] = scale_base["ms_per_step"]
+            result["scale_efficiency"] = round(scale_base["ms_per_step"] / (n * result["scale_ms_per_step"]), 4)
+    if n > 1 and "collectives" in aux:
         try:
             result["collectives"] = collectives_leg(dist, dev, n, None if direct_fell_back else direct)
         except Exception as exc:
@@ -555,7 +778,7 @@ def main():
         if direct is not None:
             direct.close()
         dist.destroy_process_group()
-    if rank == 0 and not args.no_aux and not args.rehearse:
+    if rank == 0 and "e2e" in aux and not args.rehearse:
         # every bench rank has released its GPU memory; the engine starts its own one process per GPU
         port = int(os.environ.get("MASTER_PORT", "29500")) + 17
         legs = [e2e_leg(n, port, "eager", 150)]

@@ -50,7 +50,7 @@ def test_recorded_traffic_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
     import hashlib
     import json
     b = _bench()
-    value, source = b.recorded_traffic()
+    value, source = b.recorded_traffic("decode_attn_kernel<2", b.decode_bytes(256, 1024, 16, 8))
     src = os.path.join(ROOT, "light_vllm_amd", "csrc", "decode_attn.hip")
     sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
     rec = json.load(open(os.path.join(ROOT, "profiles", "decode_traffic.json")))
@@ -59,3 +59,28 @@ def test_recorded_traffic_is_tied_to_the_kernel_source(tmp_path, monkeypatch):
     else:
         assert value is None and "stale" in source["kind"]
     assert source["current_kernel_source"] == sha
+
+
+def test_recorded_traffic_matches_kernel_and_launch():
+    """A recording is used only for the kernel AND launch it was taken on."""
+    b = _bench()
+    value, source = b.recorded_traffic("decode_attn_kernel<2", 12345)     # no such launch recorded
+    assert value is None and ("no recording" in source["kind"] or "stale" in source["kind"])
+    value, source = b.recorded_traffic("no_such_kernel")
+    assert value is None
+
+
+def test_prefill_counter_record_is_tied_to_the_kernel_source():
+    import hashlib
+    import json
+    b = _bench()
+    rec = b.recorded_prefill_counters()
+    path = os.path.join(ROOT, "profiles", "prefill_counters.json")
+    if not os.path.exists(path):
+        assert rec is None
+        return
+    sha = hashlib.sha256(open(os.path.join(ROOT, "light_vllm_amd", "csrc", "prefill_attn.hip"), "rb").read()).hexdigest()[:16]
+    if json.load(open(path)).get("kernel_source_sha16") == sha:
+        assert 0 < rec["mfma_pipe_busy_fraction"] < 1
+    else:
+        assert "stale" in rec["kind"] and "mfma_pipe_busy_fraction" not in rec

@@ -36,3 +36,8 @@ def test_bench_gpus2_rehearsal(gpu):
     assert rec["value"] > 0 and rec["ms_per_step"] > 0 and not rec.get("comm_failed")
     assert rec["roofline"]["bytes_per_launch"] == 8 * 32768 * 4 * 128 * 4 + 2 * 8 * 16 * 128 * 2 + 4 * 8 + 4 * 8 * 128
     assert "decode_256KiB" in rec["collectives"] and "direct_us" in rec["collectives"]["decode_256KiB"]
+    # one workload comparable at every N: config 4 at TP = N beside its TP = 1 base of the same run
+    assert rec["scale_value"] == rec["value"] and rec["scale_ms_per_step"] == rec["ms_per_step"]
+    assert "config 4" in rec["scale_workload"] and "TP=2" in rec["scale_workload"]
+    assert rec["config4_tp1"]["ms_per_step"] == rec["scale_base_ms_per_step"] > 0
+    assert abs(rec["scale_efficiency"] - rec["scale_base_ms_per_step"] / (2 * rec["scale_ms_per_step"])) < 1e-3

@@ -319,6 +319,10 @@ def main():
         rows.append(decode_case(32, 32768, 32, 8, graph=True))
         rows.append(decode_case(32, 32768, 4, 1, graph=True))
         rows.append(decode_case(64, 4096, 32, 8, graph=True))
+    if args.what == "decode_c5":         # Qwen3-32B TP=8 shard at 32k context: eager vs replayed, split counts
+        for graph in (False, True):
+            for ns in (0, 1, 2, 4, 8):
+                rows.append(decode_case(64, 32768, 8, 1, nsplit=ns, graph=graph))
     if args.what == "decode_g8":
         rows.append(decode_case(256, 1024, 64, 8))
     if args.what == "decode_ragged1":    # ragged batches, one pass, graph replay: for comparing builds
