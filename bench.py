@@ -475,10 +475,19 @@ def time_all_reduce(fn, x, iters=50):
 def collectives_leg(dist, dev, n, direct):
     """Average time of the in-place bf16 sum all-reduce of the TP model at its decode-sized
     messages ([32, 4096] and [256, 4096]) on the direct IPC path and on RCCL, and at the
-    prefill-sized message ([16384, 4096], RCCL only); busbw = 2(n-1)/n * bytes / t.
+    prefill-sized message ([16384, 4096], RCCL only); busbw = 2(n-1)/n * bytes / t. Then a sweep of
+    the direct path from 64 KiB to 8 MiB under both of its algorithms, from which the one-shot /
+    two-shot threshold (lv_comm_set_one_shot_inflow) is read off after a run across GPUs.
     A failure of the direct path on this rank is recorded per message and never skips a later
     RCCL call: every rank issues the same torch.distributed collectives in the same order."""
     out = {}
+
+    def direct_time(x, algorithm):
+        us = time_all_reduce(lambda t: direct.all_reduce(t, algorithm), x)
+        if direct.failed():
+            raise RuntimeError("a peer did not arrive within the communicator's timeout")
+        return us
+
     for name, rows in (("decode_256KiB", 32), ("decode_2MiB", 256), ("prefill_128MiB", 16384)):
         x = torch.ones(rows, 4096, dtype=torch.bfloat16, device=dev)
         rec = {}
@@ -488,16 +497,31 @@ def collectives_leg(dist, dev, n, direct):
             rec["rccl_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
         if direct is not None and direct.usable(x):
             try:
-                us = time_all_reduce(direct.all_reduce, x)
-                if direct.failed():
-                    raise RuntimeError("a peer did not arrive within the communicator's timeout")
+                us = direct_time(x, "auto")
                 rec["direct_us"] = round(us, 1)
+                rec["direct_algorithm"] = direct.algorithm_for(x.numel() * 2)
                 rec["direct_busbw_GBs"] = round(2 * (n - 1) / n * x.numel() * 2 / (us * 1e-6) / 1e9, 1)
             except Exception as exc:   # noqa: BLE001 - recorded; the RCCL sequence below stays in step
                 rec["direct_error"] = repr(exc)[:200]
                 torch.cuda.synchronize()
         out[name] = rec
         del x
+    if direct is not None:
+        sweep = {"one_shot_inflow_bytes": direct.one_shot_inflow, "sizes": {}}
+        for kib in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+            x = torch.ones(kib * 512, dtype=torch.bfloat16, device=dev)
+            rec = {"auto": direct.algorithm_for(kib * 1024)}
+            try:
+                for algorithm in ("one_shot", "two_shot"):
+                    rec[algorithm + "_us"] = round(direct_time(x, algorithm), 1)
+            except Exception as exc:   # noqa: BLE001
+                rec["error"] = repr(exc)[:200]
+                torch.cuda.synchronize()
+                sweep["sizes"][f"{kib}KiB"] = rec
+                break
+            sweep["sizes"][f"{kib}KiB"] = rec
+            del x
+        out["direct_sweep"] = sweep
     return out
 
 
@@ -706,7 +730,10 @@ def main():
                        "decode_splits": w.nsplit, "hipgraph": graphed, "rehearsal": bool(args.rehearse),
                        "all_reduce": "direct (lv_comm over IPC-mapped peer buffers)"
                                      if direct is not None and not direct_fell_back else backend,
-                       "all_reduce_bytes": msg},
+                       "all_reduce_bytes": msg,
+                       "all_reduce_algorithm": direct.algorithm_for(msg)
+                                               if direct is not None and not direct_fell_back else None,
+                       "one_shot_inflow_bytes": direct.one_shot_inflow if direct is not None else None},
             "rccl_ranks": dist.get_world_size(), "dist_backend": backend,
             "pct_hbm_peak": round(100.0 * roof["frac"], 2), "roofline": roof})
         if note:

@@ -83,11 +83,23 @@ int lv_comm_all_reduce(lv_comm_t* comm, void* data, size_t count, int algorithm,
  *   x = bf16(s * rsqrt(mean(s^2) + eps)) * weight
  * x, residual: [rows, hidden] bf16, contiguous, in place; weight: [hidden] bf16. Same bits as
  * lv_comm_all_reduce(x) followed by lv_add_rms_norm(x, residual, weight). One exchange (the one-shot
- * form): meant for the message sizes lv_comm_all_reduce serves in one shot. hidden: a multiple of 8
+ * form): meant for the message sizes lv_comm_all_reduce serves in one shot (at the default threshold and
+ * hidden 4096: up to 256 rows at 2 ranks, 85 at 4, 36 at 8; callers send larger messages through
+ * lv_comm_all_reduce, which goes two shot there, and lv_add_rms_norm). hidden: a multiple of 8
  * up to 8192; rows * hidden * 2 <= LV_COMM_MAX_BYTES. The usual collective rules apply.
  */
 int lv_comm_all_reduce_add_rms_norm(lv_comm_t* comm, void* x, void* residual, const void* weight, int64_t rows,
                                     int hidden, float eps, lv_stream_t stream);
+
+/*
+ * LV_COMM_ALGO_AUTO serves a message in one shot while (world_size - 1) * bytes, what one shot moves
+ * into every rank, stays within this many bytes, and in two shots beyond. Default 2 MiB (or the
+ * environment's LV_COMM_ONE_SHOT_INFLOW_BYTES when the communicator is created); a figure derived from
+ * byte counts that the first run across GPUs should replace (bench.py --gpus N reports both
+ * algorithms from 64 KiB to 8 MiB). Must be set to the same value on every rank, between calls.
+ */
+int lv_comm_set_one_shot_inflow(lv_comm_t* comm, size_t bytes);
+size_t lv_comm_one_shot_inflow(lv_comm_t* comm);
 
 /* 0 while healthy; non-zero once a kernel of this rank has given up waiting (host-visible word,
  * no device synchronisation). */

@@ -54,6 +54,8 @@ SIGNATURES = {
     "lv_comm_connect": (c_int, [c_void_p, c_char_p]),
     "lv_comm_all_reduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "lv_comm_failed": (c_int, [c_void_p]),
+    "lv_comm_set_one_shot_inflow": (c_int, [c_void_p, c_size_t]),
+    "lv_comm_one_shot_inflow": (c_size_t, [c_void_p]),
     "lv_comm_destroy": (c_int, [c_void_p]),
 }
 

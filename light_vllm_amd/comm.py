@@ -35,12 +35,26 @@ class DirectAllReduce:
             mine = ctypes.create_string_buffer(HANDLE_BYTES)
             _lib.check(self._lib.lv_comm_get_handle(self._comm, mine), "lv_comm_get_handle")
         self.handle = bytes(mine.raw)
+        self._inflow = int(self._lib.lv_comm_one_shot_inflow(self._comm))     # cached: usable_fused runs per layer
 
     def connect(self, handles) -> None:
         """handles: every rank's `handle` in rank order."""
         assert len(handles) == self.world_size and all(isinstance(h, bytes) and len(h) == HANDLE_BYTES for h in handles)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.lv_comm_connect(self._comm, b"".join(handles)), "lv_comm_connect")
+
+    @property
+    def one_shot_inflow(self) -> int:
+        """"auto" goes two shot once (world_size - 1) * bytes passes this (lv_comm_one_shot_inflow)."""
+        return int(self._lib.lv_comm_one_shot_inflow(self._comm)) if self._comm is not None else 0
+
+    def set_one_shot_inflow(self, nbytes: int) -> None:
+        """The same value on every rank (create_for_group takes rank 0's)."""
+        _lib.check(self._lib.lv_comm_set_one_shot_inflow(self._comm, int(nbytes)), "lv_comm_set_one_shot_inflow")
+        self._inflow = int(nbytes)
+
+    def algorithm_for(self, nbytes: int) -> str:
+        return "two_shot" if (self.world_size - 1) * nbytes > self.one_shot_inflow else "one_shot"
 
     def usable(self, t: torch.Tensor) -> bool:
         nbytes = t.numel() * t.element_size()
@@ -60,7 +74,7 @@ class DirectAllReduce:
 
     def usable_fused(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor) -> bool:
         """x, residual [rows, hidden] and weight [hidden] fit all_reduce_add_rms_norm, and the message
-        is one the plain all-reduce would serve in one shot ((world - 1) * bytes <= 2 MiB)."""
+        is one the plain all-reduce would serve in one shot ((world - 1) * bytes <= one_shot_inflow)."""
         if not (self.usable(x) and x.dim() == 2 and residual.shape == x.shape and residual.dtype == x.dtype
                 and residual.is_contiguous() and residual.device == x.device and residual.data_ptr() % 16 == 0):
             return False
@@ -68,7 +82,7 @@ class DirectAllReduce:
         nbytes = x.numel() * 2
         return (weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == hidden
                 and weight.device == x.device and weight.data_ptr() % 16 == 0
-                and hidden % 8 == 0 and hidden <= 8192 and (self.world_size - 1) * nbytes <= (2 << 20))
+                and hidden % 8 == 0 and hidden <= 8192 and (self.world_size - 1) * nbytes <= self._inflow)
 
     def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
         """x <- RMSNorm(all_reduce(x) + residual) * weight, residual <- all_reduce(x) + residual, both in
@@ -113,13 +127,15 @@ def _self_test(comm: DirectAllReduce) -> str:
 
 
 def create_for_group(device: torch.device, timeout_ms: int = 0, group=None,
-                     self_test: bool = True) -> Optional[DirectAllReduce]:
+                     self_test: bool = True, one_shot_inflow_bytes: Optional[int] = None) -> Optional[DirectAllReduce]:
     """Collective over `group`: every rank builds its end, the handles travel through the group, every
     rank maps its peers, and (self_test) known-answer sums run through both algorithms. Each local
     step is followed by an exchange of its outcome, so that a rank on which a step fails (IPC can be
     unavailable, e.g. ranks in different containers) never leaves the others waiting in a different
     collective: all ranks keep the communicator or all drop it together and stay on
-    torch.distributed. Returns None then."""
+    torch.distributed. Returns None then.
+    one_shot_inflow_bytes: the one-shot / two-shot threshold of "auto" (None: the library's default or
+    LV_COMM_ONE_SHOT_INFLOW_BYTES); whatever rank 0 ends up with is set on every rank."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
 
     def agree(ok: bool, payload):
@@ -144,9 +160,13 @@ def create_for_group(device: torch.device, timeout_ms: int = 0, group=None,
             err = repr(exc)
     else:
         err = f"{world} ranks (2..8 supported)"
-    ok, payloads = agree(comm is not None, comm.handle if comm is not None else err)
+    if comm is not None and one_shot_inflow_bytes is not None:
+        comm.set_one_shot_inflow(one_shot_inflow_bytes)
+    ok, payloads = agree(comm is not None, (comm.handle, comm.one_shot_inflow) if comm is not None else err)
     if not ok:
-        return give_up(comm, payloads)
+        return give_up(comm, [p if isinstance(p, str) else "" for p in payloads])
+    comm.set_one_shot_inflow(payloads[0][1])          # one threshold for the group: rank 0's
+    payloads = [p[0] for p in payloads]
     err = ""
     try:
         comm.connect(payloads)

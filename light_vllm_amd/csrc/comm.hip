@@ -315,6 +315,7 @@ struct lv_comm {
   int rank = 0, world = 0, device = -1;
   bool connected = false;
   long long timeout_ticks = 0;
+  size_t one_shot_inflow = 2u << 20;                   // AUTO: two shot once (world - 1) x bytes passes this
   unsigned char* mine = nullptr;                       // this rank's shared allocation
   unsigned char* base[LV_COMM_MAX_RANKS] = {};         // every rank's allocation as mapped here
   uint32_t* epoch = nullptr;
@@ -343,6 +344,11 @@ int lv_comm_create(int rank, int world_size, int timeout_ms, lv_comm_t** comm) {
   c->rank = rank;
   c->world = world_size;
   c->timeout_ticks = static_cast<long long>(timeout_ms > 0 ? timeout_ms : 10000) * 100000;   // 100 MHz
+  if (const char* env = getenv("LV_COMM_ONE_SHOT_INFLOW_BYTES")) {
+    char* end = nullptr;
+    const unsigned long long v = strtoull(env, &end, 10);
+    if (end != env) c->one_shot_inflow = static_cast<size_t>(v);
+  }
   int rc = LV_OK;
   do {
     hipError_t e = hipGetDevice(&c->device);
@@ -426,6 +432,14 @@ int lv_comm_connect(lv_comm_t* c, const void* all_handles) {
   return LV_OK;
 }
 
+int lv_comm_set_one_shot_inflow(lv_comm_t* c, size_t bytes) {
+  if (!c) return fail(LV_ERR_INVALID_ARGUMENT, "set_one_shot_inflow: null communicator");
+  c->one_shot_inflow = bytes;
+  return LV_OK;
+}
+
+size_t lv_comm_one_shot_inflow(lv_comm_t* c) { return c ? c->one_shot_inflow : 0; }
+
 int lv_comm_failed(lv_comm_t* c) {
   if (!c) return 1;
   return *reinterpret_cast<volatile int*>(c->host_failed) != 0;
@@ -464,10 +478,11 @@ int lv_comm_all_reduce(lv_comm_t* c, void* data, size_t count, int algorithm, lv
   hipStream_t s = static_cast<hipStream_t>(stream);
   // One shot moves (world - 1) x the message into every rank, two shot 2 (world - 1) / world of it in
   // two exchanges: two shot once the one-shot inflow passes 2 MiB (8 ranks: messages over 292 KiB,
-  // 4 ranks: over 683 KiB, 2 ranks: never). Set from the byte counts alone; no run across two GPUs
-  // has tuned it yet.
+  // 4 ranks: over 683 KiB, 2 ranks: never). The 2 MiB default is set from the byte counts alone (no
+  // run across two GPUs has tuned it yet): lv_comm_set_one_shot_inflow / LV_COMM_ONE_SHOT_INFLOW_BYTES
+  // move it, the same on every rank.
   const bool two = algorithm == LV_COMM_ALGO_TWO_SHOT ||
-                   (algorithm == LV_COMM_ALGO_AUTO && static_cast<size_t>(c->world - 1) * bytes > (2u << 20));
+                   (algorithm == LV_COMM_ALGO_AUTO && static_cast<size_t>(c->world - 1) * bytes > c->one_shot_inflow);
   if (two) {
     switch (c->world) {
       case 2: hipLaunchKernelGGL((allreduce_kernel<2, true>), grid, block, 0, s, p); break;

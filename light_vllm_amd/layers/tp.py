@@ -60,9 +60,13 @@ def gather_to_rank0(t):
     (reference: layers/embed_head.py:180-192)."""
     if _CARRIER is not None:
         return _CARRIER.gather_to_rank0(t)
-    parts = [torch.empty_like(t) for _ in range(tp_size())] if tp_rank() == 0 else None
-    dist.gather(t, parts, 0)
-    return parts
+    # An all-gather, although only rank 0 consumes the result: on RCCL a gather is a series of
+    # point-to-point receives into rank 0, an all-gather one collective that uses every xGMI link
+    # (the logits are 2 * vocab / tp bytes per sequence and rank: 9.7 MB per rank at 256 sequences
+    # and tp = 8). The other ranks drop their copy.
+    parts = [torch.empty_like(t) for _ in range(tp_size())]
+    dist.all_gather(parts, t.contiguous())
+    return parts if tp_rank() == 0 else None
 
 
 def all_gather(t):

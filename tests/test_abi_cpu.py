@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_decode_attn_planned", "lv_prefill_max_workspace_bytes",
         "lv_prefill_num_splits", "lv_prefill_workspace_bytes", "lv_prefill_tile_rows", "lv_prefill_order_columns",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
-        "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm"])
+        "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm", "lv_comm_set_one_shot_inflow", "lv_comm_one_shot_inflow"])
 
 
 def test_library_exports_every_declared_symbol():

@@ -36,6 +36,11 @@ def test_bench_gpus2_rehearsal(gpu):
     assert rec["value"] > 0 and rec["ms_per_step"] > 0 and not rec.get("comm_failed")
     assert rec["roofline"]["bytes_per_launch"] == 8 * 32768 * 4 * 128 * 4 + 2 * 8 * 16 * 128 * 2 + 4 * 8 + 4 * 8 * 128
     assert "decode_256KiB" in rec["collectives"] and "direct_us" in rec["collectives"]["decode_256KiB"]
+    assert rec["config"]["all_reduce_algorithm"] == "one_shot" and rec["config"]["one_shot_inflow_bytes"] == 2 << 20
+    sweep = rec["collectives"]["direct_sweep"]
+    assert sweep["one_shot_inflow_bytes"] == 2 << 20 and set(sweep["sizes"]) >= {"64KiB", "2048KiB", "8192KiB"}
+    assert all(v["one_shot_us"] > 0 and v["two_shot_us"] > 0 for v in sweep["sizes"].values())
+    assert sweep["sizes"]["8192KiB"]["auto"] == "two_shot" and sweep["sizes"]["64KiB"]["auto"] == "one_shot"
     # one workload comparable at every N: config 4 at TP = N beside its TP = 1 base of the same run
     assert rec["scale_value"] == rec["value"] and rec["scale_ms_per_step"] == rec["ms_per_step"]
     assert "config 4" in rec["scale_workload"] and "TP=2" in rec["scale_workload"]

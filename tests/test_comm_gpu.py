@@ -144,7 +144,10 @@ def _worker(rank, world, port, out_dir, rounds):
     # replays (a valid sum), then rank 0 replays the SAME graph alone: nobody answers, the wait
     # inside the replayed kernel runs out, and no host call is there to notice - the failure word
     # the host reads after the replay (what ModelRunner.run checks after every step) is the report.
-    c2 = lvcomm.create_for_group(dev, timeout_ms=300, self_test=False)   # late peers must not trip the set-up check
+    # (ranks ask for different one-shot thresholds: the group settles on rank 0's)
+    c2 = lvcomm.create_for_group(dev, timeout_ms=300, self_test=False,   # late peers must not trip the set-up check
+                                 one_shot_inflow_bytes=(1 << 20) if rank == 0 else (4 << 20))
+    res["inflow"] = [c.one_shot_inflow, c2.one_shot_inflow, c2.algorithm_for(2 << 20), c.algorithm_for(2 << 20 if world == 2 else 64 << 10)]
     z = torch.ones(4096, dtype=torch.bfloat16, device=dev)
     dist.barrier()
     c2.all_reduce(z)                     # warm run, every rank
@@ -202,6 +205,7 @@ def test_direct_all_reduce_shared_gpu(gpu, tmp_path, world):
         assert res["calls"] == rounds * 2 * len(SIZES)
         assert res["failed_after_use"] is False
         assert res["joint_replay_ok"] is True
+        assert res["inflow"] == [2 << 20, 1 << 20, "two_shot", "one_shot"]
         assert res["fused_cases"] >= (3 if world == 8 else 6)
         if r == 0:
             print(f"world {world}: lone call gave up after {res['timeout_ms']:.0f} ms; [32, 4096] all-reduce + add + RMSNorm "
