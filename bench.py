@@ -355,7 +355,7 @@ def prefill_variant_leg(ops, dev, lens, Hq, Hkv, cached=0, iters=30, warmup=20):
     out = torch.empty_like(q)
     cu_q = torch.tensor([0] + torch.tensor(lens_q).cumsum(0).tolist(), dtype=torch.int32, device=dev)
     cu_k = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=dev)
-    order = ops.prefill_tile_order(lens_q, lens, Hq, Hkv, dev)
+    order = ops.prefill_tile_order(lens_q, lens, Hq, Hkv, dev, paged=cached > 0)
     if cached:
         need = [-(-n // BLOCK) for n in lens]
         nblk = sum(need)

@@ -192,6 +192,19 @@ int lv_silu_and_mul(const void* x, void* out, int64_t x_stride0, int64_t out_str
  *   all XCDs, and a table that keeps a sequence's tiles in one or two columns lets an XCD's L2 fetch
  *   the stream once; rows should go heaviest (most visible keys) first. No counterpart in the
  *   reference call; light_vllm_amd/prefill_order.py builds such a table.
+ * tile_order_lanes: 0 for the table above. > 0 (= lv_prefill_order_lanes(num_heads, num_kv_heads)):
+ *   tile_order is an ITEM table for the long-prompt kernel (max_seqlen_q >= 2048 or
+ *   LV_PREFILL_KERNEL_PP; one KV pass): the launch keeps one workgroup per compute unit resident and
+ *   each walks a list of query tiles instead of ending after one, the next tile's Q rows and first
+ *   K/V tiles arriving while the current one is computed. Layout int32 [depth][lanes][C][8]
+ *   (tile_order_len counts ints; 32-byte aligned); workgroup (query head, column c, lane r) serves
+ *   entries [0][r][c], [1][r][c], ... up to the first whose second word is <= 0. An entry is
+ *   {first row of the tile in q / o, its valid rows (1 .. tile_order_rows), last key visible to its first
+ *   row (row i of the tile sees keys <= that + i: bottom-right aligned causal mask), first packed K/V
+ *   row of its sequence (paged: the sequence's index into block_table), keys of its sequence, 0, 0, 0},
+ *   i.e. what cu_seqlens_q / cu_seqlens_k say about the tile, which the kernel then does not read:
+ *   unlike the code table, a wrong item table gives wrong results (it is trusted like cu_seqlens).
+ *   The host balances the lists (prefill_order.build_item_table: longest-processing-time-first).
  */
 int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int64_t q_stride0, int64_t k_stride0, int64_t v_stride0, int64_t o_stride0,
@@ -201,7 +214,7 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o,
                     int num_heads, int num_kv_heads, int head_dim, float scale,
                     int64_t total_q, void* workspace, size_t workspace_bytes, int num_splits,
                     const int32_t* tile_order, int tile_order_len, int tile_order_rows,
-                    int kernel_hint, lv_stream_t stream);
+                    int tile_order_lanes, int kernel_hint, lv_stream_t stream);
 
 /* Query rows per tile of the kernel lv_prefill_attn runs for these arguments (128 or 256; 0 for an
  * unknown kernel_hint). num_splits as resolved (lv_prefill_num_splits for 0). */
@@ -209,6 +222,10 @@ int lv_prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint);
 
 /* Columns of a tile_order table: 8 / num_kv_heads for 1, 2 or 4 kv heads, else 1. */
 int lv_prefill_order_columns(int num_kv_heads);
+
+/* Lanes of an item table (tile_order_lanes): lists per (query head, column), so that the launch is one
+ * workgroup per compute unit: 256 / (num_heads * columns), at least 1. */
+int lv_prefill_order_lanes(int num_heads, int num_kv_heads);
 
 /* Split count lv_prefill_attn uses for num_splits == 0 on these static shapes. */
 int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads);

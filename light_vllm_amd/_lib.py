@@ -31,7 +31,8 @@ SIGNATURES = {
     "lv_prefill_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                 c_int, c_int, c_int, c_float, c_int64, c_void_p, c_size_t, c_int,
-                                c_void_p, c_int, c_int, c_int, c_void_p]),
+                                c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lv_prefill_order_lanes": (c_int, [c_int, c_int]),
     "lv_prefill_tile_rows": (c_int, [c_int, c_int, c_int]),
     "lv_prefill_order_columns": (c_int, [c_int]),
     "lv_comm_all_reduce_add_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

@@ -263,7 +263,7 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
                     int block_table_stride, int block_size, int num_heads, int num_kv_heads,
                     int head_dim, float scale, int64_t total_q, void* workspace, size_t workspace_bytes,
                     int num_splits, const int32_t* tile_order, int tile_order_len, int tile_order_rows,
-                    int kernel_hint, lv_stream_t stream) {
+                    int tile_order_lanes, int kernel_hint, lv_stream_t stream) {
   if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0 || num_heads <= 0 || num_kv_heads <= 0)
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: negative size");
   if (head_dim != kHeadDim) return fail(LV_ERR_UNSUPPORTED, "prefill: head_dim %d != 128", head_dim);
@@ -335,15 +335,30 @@ int lv_prefill_attn(const void* q, const void* k, const void* v, void* o, int64_
   p.order_cols = 1;
   p.order_len = 0;
   p.order_rows = 0;
+  p.order_lanes = 0;
   if (tile_order) {
     const int cols = prefill_order_columns(num_kv_heads);
-    if (tile_order_len <= 0 || tile_order_len % cols != 0)
+    if (tile_order_lanes < 0) return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order_lanes %d", tile_order_lanes);
+    if (tile_order_lanes > 0) {
+      // an item table for persistent workgroups: 8 ints per entry, [depth][lanes][columns]
+      if (tile_order_lanes != prefill_order_lanes(num_heads, num_kv_heads))
+        return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order_lanes %d, this launch needs %d (lv_prefill_order_lanes)",
+                    tile_order_lanes, prefill_order_lanes(num_heads, num_kv_heads));
+      if (tile_order_len <= 0 || tile_order_len % (8 * cols * tile_order_lanes) != 0)
+        return fail(LV_ERR_INVALID_ARGUMENT, "prefill: an item table of %d ints is not a multiple of 8 x %d columns x %d lanes",
+                    tile_order_len, cols, tile_order_lanes);
+      if (nsplit != 1) return fail(LV_ERR_INVALID_ARGUMENT, "prefill: an item table serves one KV pass (num_splits 1)");
+      if ((reinterpret_cast<uintptr_t>(tile_order) & 31u) != 0)
+        return fail(LV_ERR_UNSUPPORTED, "prefill: an item table must be 32-byte aligned");
+    } else if (tile_order_len <= 0 || tile_order_len % cols != 0) {
       return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order_len %d must be a positive multiple of %d "
                   "(lv_prefill_order_columns)", tile_order_len, cols);
+    }
     p.tile_order = tile_order;
     p.order_cols = cols;
     p.order_len = tile_order_len;
     p.order_rows = tile_order_rows;
+    p.order_lanes = tile_order_lanes;
   }
   return launch_prefill_attn(p, static_cast<hipStream_t>(stream));
 }
@@ -353,6 +368,11 @@ int lv_prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint) {
 }
 
 int lv_prefill_order_columns(int num_kv_heads) { return prefill_order_columns(num_kv_heads); }
+
+int lv_prefill_order_lanes(int num_heads, int num_kv_heads) {
+  if (num_heads <= 0 || num_kv_heads <= 0) return 0;
+  return prefill_order_lanes(num_heads, num_kv_heads);
+}
 
 int lv_prefill_num_splits(int batch, int max_seqlen_q, int max_seqlen_k, int num_heads) {
   return prefill_heuristic_splits(batch, max_seqlen_q, max_seqlen_k, num_heads);

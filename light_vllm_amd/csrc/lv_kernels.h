@@ -44,7 +44,12 @@ struct PrefillParams {
   int order_cols;              // columns of the table: 8 / num_kv_heads for 1, 2, 4 kv heads, else 1
   int64_t order_len;
   int order_rows;              // query rows per tile the table was built for (must match the kernel's)
+  int order_lanes;             // 0: tile_order holds codes b * qtiles + t. > 0: it holds 8-int entries
+                               // {q row, valid rows, causal limit of the first row, packed K row or sequence,
+                               // keys, 0, 0, 0}, [depth][lanes][order_cols]: the lists persistent workgroups walk
 };
+// Lanes of an item table: workgroups per (query head, table column) that one launch keeps resident.
+int prefill_order_lanes(int num_heads, int num_kv_heads);
 
 // Query rows per workgroup tile of the prefill kernel a launch with these arguments runs.
 int prefill_tile_rows(int max_seqlen_q, int num_splits, int kernel_hint);

@@ -21,6 +21,8 @@
 // tile) and prefill_pp_kernel (8 waves in two groups that alternate matrix and load clusters).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lv_kernels.h"
 
 namespace lv {
@@ -79,6 +81,9 @@ __device__ unsigned long long* g_lv_stamp_buf = nullptr;
 __device__ unsigned long long* g_lv_tl_buf = nullptr;
 #define LV_TL_DECL unsigned long long tl_t[6] = {0, 0, 0, 0, 0, 0};
 #define LV_TL(i) { __builtin_amdgcn_sched_barrier(0); tl_t[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+#define LV_TLA(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tl_now = __builtin_amdgcn_s_memrealtime(); \
+  tl_t[i] += tl_now - tl_prev; tl_prev = tl_now; __builtin_amdgcn_sched_barrier(0); }
+#define LV_TLA_START unsigned long long tl_prev = __builtin_amdgcn_s_memrealtime(); tl_t[2] = tl_t[3] = tl_t[4] = 0;
 #define LV_TL_FLUSH if (g_lv_tl_buf && threadIdx.x == 0) { \
   unsigned long long* d = g_lv_tl_buf + static_cast<size_t>(blockIdx.x) * 8; \
   for (int i = 0; i < 6; ++i) d[i] = tl_t[i]; \
@@ -86,6 +91,8 @@ __device__ unsigned long long* g_lv_tl_buf = nullptr;
 #else
 #define LV_TL_DECL
 #define LV_TL(i)
+#define LV_TLA(i)
+#define LV_TLA_START
 #define LV_TL_FLUSH
 #endif
 
@@ -705,40 +712,125 @@ void prefill_attn_kernel(const PrefillParams p) {
 #ifndef LV_PP_LPRIO
 #define LV_PP_LPRIO 2
 #endif
-template <bool PAGED>
+// PERSIST (launched when the caller passes an item table, PrefillParams::order_lanes > 0): one
+// workgroup per compute unit walks a list of query tiles the host has balanced for it instead of
+// ending after one. What a workgroup pays per tile shrinks to reading its Q fragments and storing its
+// output: the next tile's Q rows and first two K tiles arrive by LDS-DMA while the current tile is
+// computed (Q into the image behind the slots, which is free once the fragments are in registers; K
+// into a second pair of K slots that the tiles use alternately), its first V tile is requested
+// before the output stores, and its lengths come from the host's table entry (one scalar load
+// instead of three dependent ones). Measured on 4 x 4096 tokens, 32q/8kv, non-persistent: 2.8 us
+// from entry to Q fragments, 1.3 us to the first published K/V tiles, 1.4 us of store tail and 1.4 us
+// until the next workgroup starts on the compute unit, against 63 us in the tile loop.
+template <bool PAGED, bool PERSIST>
 __global__ __launch_bounds__(512, 2)
 void prefill_pp_kernel(const PrefillParams p) {
   constexpr int NW = 8;
   constexpr int BM = 32 * NW;
   constexpr int NST = 2;      // 16-byte chunks of K (and of V) each thread stages per tile
   constexpr int RSTEP = 32;   // tile rows between them
-  // slot s: K at 2s, V at 2s+1; behind the slots a 64-KiB image of the workgroup's Q tile (8 KiB
-  // per wave, that wave's 32 rows in the K tiles' swizzled row layout)
+  // LDS: K slots s = 0, 1 at kKOff + s * kKStep, V slots at kVOff + s * kVStep, then a 64-KiB image of
+  // the workgroup's Q tile (8 KiB per wave, that wave's 32 rows in the K tiles' swizzled row layout);
+  // PERSIST: behind it a second pair of K slots (the K slots in use alternate between the pairs
+  // from one query tile to the next: kring = 0 or kRingB is added to every K address)
+#ifndef LV_PX
+#define LV_PX 0      // diagnostic builds only: 1 = __syncthreads() barriers, 2 = compiler-visible LDS stores, 4 = slot layout of the one-tile kernel (with LV_PABL 3)
+#endif
+  constexpr bool kNewLayout = PERSIST && !(LV_PX & 4);
+  constexpr int kKOff = 0, kKStep = kNewLayout ? kTileBytes : 2 * kTileBytes;
+  constexpr int kVOff = kNewLayout ? 2 * kTileBytes : kTileBytes, kVStep = kNewLayout ? kTileBytes : 2 * kTileBytes;
   constexpr int kQImg = 4 * kTileBytes;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * kTileBytes + BM * kHeadDim * 2];
+  constexpr int kRingB = kQImg + BM * kHeadDim * 2;
+  constexpr int kLdsBytes = kRingB + (PERSIST ? 2 * kTileBytes : 0);
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kLdsBytes];
   lds_byte* const lds3 = (lds_byte*)lds;
 
   LV_TL_DECL
   LV_TL(0)
-  TileWork tw;
-  if (!tile_of_block<BM>(p, tw)) return;   // launched with nsplit == 1
-  const int kvh = tw.kvh, hq = tw.hq, q0 = tw.q0, b = tw.b;
-  const int q_start = p.cu_q[b];
-  const int Lq = p.cu_q[b + 1] - q_start;
-  const int k_start = p.cu_k[b];
-  const int Lk = p.cu_k[b + 1] - k_start;
-  if (q0 >= Lq) return;
-  const int coff = Lk - Lq;
-
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int lane = tid & 63;
   const int h = lane >> 5;
   const int c = lane & 31;
-  const int wrow0 = q0 + wave * 32;
-  const int my_row = wrow0 + c;
-  const int my_lim = my_row + coff;
+
+  // ---- what this workgroup serves. Per query tile: qrow0 = row of q / o of the tile's first row,
+  // nrows = its valid rows (1..256), lim0 = last visible key of its first row (row r sees keys
+  // <= lim0 + r), Lk keys starting at packed row kref (PAGED: of sequence kref's block table).
+  // Workgroup barrier of the tile loop. PERSIST keeps LDS-DMA copies (the next query tile's rows) in
+  // flight across these barriers; __syncthreads() would drain them (its fence waits for every
+  // outstanding LDS write), so there the barrier is the bare instruction behind a wait for this
+  // wave's own LDS stores and loads. The copies are waited for (vmcnt(0)) once, after the tile loop.
+  auto wg_barrier = [&]() {
+    if constexpr (PERSIST && !(LV_PX & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+  };
+  // Lane id recomputed where a query tile begins or ends (PERSIST): values derived from it there are
+  // then not carried, in registers the tile loop has none to spare of, across the loop (hipcc spills
+  // them otherwise, and every reload waits for all outstanding loads, the DMA copies included).
+  auto fresh_lane = [&]() -> int {
+    if constexpr (PERSIST) {
+      int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(l));
+      return l;
+    } else {
+      return lane;
+    }
+  };
+  // PERSIST stores outputs inside its loop over query tiles; for hipcc those stores might alias the
+  // item table and the block table, so it would read both with vector loads (and wait for every
+  // outstanding load, the DMA copies included, at each). Neither is written during the launch: read
+  // through the constant address space they stay scalar loads.
+  typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
+  typedef std::conditional_t<PERSIST, const_i32_ptr, const int32_t*> table_ptr;
+  const table_ptr tile_table = (table_ptr)p.tile_order;
+  const table_ptr block_table = (table_ptr)p.block_table;
+  int kvh, hq;
+  int qrow0, nrows, lim0, kref, Lk;
+  [[maybe_unused]] int it_col = 0, it_lane = 0, it_lanes = 1, it_depth = 0, it_k = 0;
+  auto item_ptr = [&](int k) -> table_ptr {     // PERSIST: table entry k of this workgroup's lane
+    return tile_table + (static_cast<int64_t>(k * it_lanes + it_lane) * p.order_cols + it_col) * 8;
+  };
+  if constexpr (PERSIST) {
+    const int G = p.num_heads / p.num_kv_heads;
+    int wg = blockIdx.x;
+    kvh = wg % p.num_kv_heads;
+    wg /= p.num_kv_heads;
+    it_col = wg % p.order_cols;
+    wg /= p.order_cols;
+    hq = kvh * G + wg % G;
+    it_lane = wg / G;
+    it_lanes = p.order_lanes;
+    it_depth = static_cast<int>(p.order_len / (8 * static_cast<int64_t>(p.order_cols) * it_lanes));
+    if (it_depth <= 0) return;
+    const table_ptr e = item_ptr(0);
+    qrow0 = e[0]; nrows = e[1]; lim0 = e[2]; kref = e[3]; Lk = e[4];
+    if (nrows <= 0) return;
+  } else {
+    TileWork tw;
+    if (!tile_of_block<BM>(p, tw)) return;   // launched with nsplit == 1
+    kvh = tw.kvh; hq = tw.hq;
+    const int q_start = p.cu_q[tw.b];
+    const int Lq = p.cu_q[tw.b + 1] - q_start;
+    const int k_start = p.cu_k[tw.b];
+    Lk = p.cu_k[tw.b + 1] - k_start;
+    if (tw.q0 >= Lq) return;
+    qrow0 = q_start + tw.q0;
+    nrows = min(BM, Lq - tw.q0);
+    lim0 = tw.q0 + Lk - Lq;
+    kref = PAGED ? tw.b : k_start;
+  }
+  // derived per query tile
+  int wlim0, my_lim, ntiles;
+  table_ptr bt_row;
+  auto derive = [&]() {
+    wlim0 = lim0 + wave * 32;              // causal limit of the wave's first row
+    my_lim = wlim0 + (fresh_lane() & 31);
+    const int max_key = min(lim0 + nrows - 1, Lk - 1);
+    ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
+    bt_row = PAGED ? block_table + static_cast<int64_t>(kref) * p.bt_stride : nullptr;
+  };
+  derive();
 
   // Q^T fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e) so scores come out
   // of the MFMA in log2 units
@@ -754,29 +846,26 @@ void prefill_pp_kernel(const PrefillParams p) {
   const float c2 = p.scale_log2e / q_pow;
   const float defer_s = kDeferLog2 / c2;
 
-  const int last_row = min(q0 + BM - 1, Lq - 1);
-  const int max_key = min(last_row + coff, Lk - 1);
-  const int ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
-
   // ---- staging (register path): chunk st_ch of tile rows st_r and st_r + 32
   const int st_ch = tid & 15;
   const int st_r = tid >> 4;
-  const int32_t* bt_row = PAGED ? p.block_table + static_cast<int64_t>(b) * p.bt_stride : nullptr;
   const uint32_t k_row_bytes = static_cast<uint32_t>(p.k_stride0) * 2u;
   const uint32_t v_row_bytes = static_cast<uint32_t>(p.v_stride0) * 2u;
   const uint32_t col_bytes = static_cast<uint32_t>(kvh * kHeadDim + 8 * st_ch) * 2u;
   const int st_lds = lds_off(st_r, st_ch);
+  int kring = 0;              // PERSIST: byte offset of the K slot pair in use (0 or kRingB)
 
   u32x4 kreg[NST], vreg[NST];
-  auto tile_row = [&](int tile) -> int64_t {  // cache / packed row of the tile's first key
+  auto tile_row_of = [&](table_ptr bt, int kr, int tile) -> int64_t {  // cache / packed row of a tile's first key
     const int kt0 = tile * BN;
     if constexpr (PAGED) {
-      const int blk = bt_row[kt0 / p.block_size];
+      const int blk = bt[kt0 / p.block_size];
       return static_cast<int64_t>(blk) * p.block_size + (kt0 % p.block_size);
     } else {
-      return static_cast<int64_t>(k_start) + kt0;
+      return static_cast<int64_t>(kr) + kt0;
     }
   };
+  auto tile_row = [&](int tile) -> int64_t { return tile_row_of(bt_row, kref, tile); };
   // per-thread byte offset inside a tile (same for every tile): the tile base stays in scalar
   // registers and the loop carries no 64-bit vector address arithmetic
   const uint32_t st_koff = static_cast<uint32_t>(st_r) * k_row_bytes + col_bytes;
@@ -792,22 +881,98 @@ void prefill_pp_kernel(const PrefillParams p) {
     for (int i = 0; i < NST; ++i)
       reg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, st_off, RSTEP * i * row_bytes, 0));
   };
-  auto write_rows = [&](int byte_off, const u32x4 (&reg)[NST]) {
-    if (LV_ABL & 16) return;
+  // the same for a tile of another query tile (PERSIST: the next one's first V tile)
+  auto load_rows_at = [&](int64_t row, int rows_valid, const uint16_t* base, uint32_t row_bytes, uint32_t st_off,
+                          u32x4 (&reg)[NST]) {
+    const char* tb = reinterpret_cast<const char*>(base) + row * row_bytes;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb), 0, static_cast<uint32_t>(rows_valid) * row_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NST; ++i)
-      *reinterpret_cast<u32x4*>(lds + byte_off + 256 * RSTEP * i + st_lds) = reg[i];
+      reg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, st_off, RSTEP * i * row_bytes, 0));
+  };
+  // K/V rows from the staging registers into an LDS slot. PERSIST issues these stores as inline
+  // asm: while LDS-DMA copies are outstanding hipcc puts a wait for ALL outstanding loads in front of
+  // every LDS store it can see (the copy might be aimed at the same bytes; it is not: the copies go
+  // to the Q image and the other K slot pair), and the tile loop lives on loads that stay in flight.
+  // The wait the store does need, for the load that fills `reg`, hipcc still places (the register is
+  // an input of the statement); wg_barrier() waits for the stores themselves.
+  uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds3));   // LDS address of the array (0)
+  auto lds_store = [&](int at, auto off_c, const u32x4& val) {   // 16 bytes to LDS byte `at` + compile-time offset
+    constexpr int OFF = decltype(off_c)::value;
+    [[maybe_unused]] const uint32_t addr = lds_base + static_cast<uint32_t>(at);
+    if constexpr (PERSIST && !(LV_PX & 2)) {
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(OFF) : "memory");
+    } else {
+      *reinterpret_cast<u32x4*>(lds + OFF + at) = val;
+    }
+  };
+  auto write_rows = [&](auto off_c, const u32x4 (&reg)[NST]) {
+    constexpr int OFF = decltype(off_c)::value;
+    if (LV_ABL & 16) return;
+    static_assert(NST == 2);
+    lds_store(st_lds, IntC<OFF>{}, reg[0]);
+    lds_store(st_lds, IntC<OFF + 256 * RSTEP>{}, reg[1]);
+  };
+  auto write_k = [&](auto off_c, const u32x4 (&reg)[NST]) {
+    constexpr int OFF = decltype(off_c)::value;
+    if (LV_ABL & 16) return;
+    int at = st_lds;
+    // st_lds + kring, formed where it is used: as a value of its own it would take one more of the
+    // registers the tile loop has none to spare of
+    if constexpr (PERSIST) asm volatile("v_add_u32 %0, %1, %2" : "=v"(at) : "v"(st_lds), "s"(kring));
+    lds_store(at, IntC<OFF>{}, reg[0]);
+    lds_store(at, IntC<OFF + 256 * RSTEP>{}, reg[1]);
+  };
+  // LDS-DMA of whole rows into the swizzled row image (one wave instruction = one 1-KiB piece = 4
+  // rows; lane l brings the 16 bytes that belong at physical chunk l & 15 of row l >> 4 of the piece).
+  // Q: rows of the query tile at q row `qr0` with `nr` valid rows, this wave's own 32 into its 8 KiB of
+  // the image. K: a 64-key tile at cache / packed row `row` with `rows_valid` keys into LDS offset
+  // `dst`, pieces wave and wave + 8. Rows past the end re-read the last valid row (masked later).
+  auto dma_q = [&](int qr0, int nr) {
+    const int ln = fresh_lane();
+    const int lrow = ln >> 4;
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      const int r = 4 * pc + lrow;                               // row of the wave's 32
+      const int lchunk = (ln & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+      const int row_ld = min(wave * 32 + r, nr - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(p.q + static_cast<int64_t>(qr0 + row_ld) * p.q_stride0 +
+                                                          hq * kHeadDim + 8 * lchunk),
+          (__attribute__((address_space(3))) void*)(lds3 + kQImg + wave * 8192 + 1024 * pc), 16, 0, 0);
+    }
+  };
+  [[maybe_unused]] auto dma_k = [&](int64_t row, int rows_valid, int dst) {
+    const int ln = fresh_lane();
+    const int lrow = ln >> 4;
+    const int lchunk = (ln & 15) ^ ((lrow << 2) | (wave & 3));   // pieces wave, wave + 8: (piece & 3) = wave & 3
+    const char* kb = reinterpret_cast<const char*>(p.k) + row * k_row_bytes +
+                     static_cast<uint32_t>(kvh * kHeadDim + 8 * lchunk) * 2u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave + 8 * i;
+      const uint32_t r = static_cast<uint32_t>(max(min(4 * piece + lrow, rows_valid - 1), 0));   // no keys: the tensor's row `row`
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(kb + r * k_row_bytes),
+          (__attribute__((address_space(3))) void*)(lds3 + dst + 1024 * piece), 16, 0, 0);
+    }
   };
 
   f32x16 oacc[4];
+  float m_run, l_run, defer_thr, pend_alpha;
+  bool pend;
+  auto reset_state = [&]() {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  float defer_thr = -INFINITY;
-  float pend_alpha = 1.f;
-  bool pend = false;
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    m_run = -INFINITY;
+    l_run = 0.f;
+    defer_thr = -INFINITY;
+    pend_alpha = 1.f;
+    pend = false;
+  };
+  reset_state();
 
   // LDS read addresses inside slot 0. The swizzled fragment addresses of prefill_attn_kernel
   // differ from one per-lane base only by XOR with compile-time constants:
@@ -817,7 +982,7 @@ void prefill_pp_kernel(const PrefillParams p) {
   const int gi = lane >> 4;
   const int tq = (lane & 15) >> 2;
   const int tp = lane & 3;
-  const int vbase0 = kTileBytes + lds_off(4 * (gi >> 1) + tq, 2 * (gi & 1) + (tp >> 1)) + 8 * (tp & 1);
+  const int vbase0 = lds_off(4 * (gi >> 1) + tq, 2 * (gi & 1) + (tp >> 1)) + 8 * (tp & 1);   // inside a V slot
 
   // K fragments of four d-steps (s0 .. s0+3) of a 32-key half
   auto load_kg = [&](bf16x8 (&kg)[4], int kbase, int byte_off, auto s0_c) {
@@ -871,7 +1036,7 @@ void prefill_pp_kernel(const PrefillParams p) {
   // causal mask of a tile that reaches the diagonal (uniform branch; runs in a load cluster)
   auto mask_tile = [&](int tile, f32x16& sa, f32x16& sb) {
     const int kt0 = tile * BN;
-    if (kt0 + 63 > wrow0 + coff) {
+    if (kt0 + 63 > wlim0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -960,20 +1125,23 @@ void prefill_pp_kernel(const PrefillParams p) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr int NPAR = PAR ^ 1;
     constexpr bool CUR = decltype(cur_c)::value != 0;
-    int kbase = kbase0, vbase = vbase0;   // opaque copies: keeps the XORs next to the reads
+    int kbase = kbase0 + kring, vbase = vbase0;   // opaque copies: keeps the XORs next to the reads
     asm volatile("" : "+v"(kbase), "+v"(vbase));
     LV_STAMP_COUNT
     bf16x8 kx[4][4];   // K fragments: [32-key half * 2 + d-step group][4]
     bf16x8 vx[3][4];   // V^T fragments: [column block][16-key step]; block 3 reuses block 0's registers
     // ---- L_K(i): loads only (vector ALU work here would compete with the partner's C cluster)
     __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
-    load_kg(kx[0], kbase, NPAR * 2 * kTileBytes, IntC<0>{});
-    load_kg(kx[1], kbase, NPAR * 2 * kTileBytes, IntC<4>{});
-    load_kg(kx[2], kbase, NPAR * 2 * kTileBytes + 8192, IntC<0>{});
-    load_kg(kx[3], kbase, NPAR * 2 * kTileBytes + 8192, IntC<4>{});
+    load_kg(kx[0], kbase, kKOff + NPAR * kKStep, IntC<0>{});
+    load_kg(kx[1], kbase, kKOff + NPAR * kKStep, IntC<4>{});
+    load_kg(kx[2], kbase, kKOff + NPAR * kKStep + 8192, IntC<0>{});
+    load_kg(kx[3], kbase, kKOff + NPAR * kKStep + 8192, IntC<4>{});
     // K(i+2) replaces K(i), last read in L_K(i-1); its rows were requested in L_K(i-1)
-    if (i + 2 < ntiles) {
-      write_rows(PAR * 2 * kTileBytes, kreg);
+    if constexpr (PERSIST && !CUR) {
+      // K(0) and K(1) came by LDS-DMA while the previous query tile was computed and K(2) was
+      // requested before this interval: nothing to publish or request here
+    } else if (i + 2 < ntiles) {
+      write_k(IntC<kKOff + PAR * kKStep>{}, kreg);
       __builtin_amdgcn_sched_barrier(0);
       load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
     }
@@ -997,7 +1165,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(0)
-    if (!(LV_ABL & 256)) __syncthreads();
+    if (!(LV_ABL & 256)) wg_barrier();
     LV_STAMP(4)
     __builtin_amdgcn_sched_barrier(0);
     // ---- C_QK(i): S(i+1) = K(i+1) Q^T, operands in registers
@@ -1026,7 +1194,7 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(1)
-    if (!(LV_ABL & 256)) __syncthreads();
+    if (!(LV_ABL & 256)) wg_barrier();
     LV_STAMP(5)
     __builtin_amdgcn_sched_barrier(0);
     // ---- L_V(i)
@@ -1034,21 +1202,21 @@ void prefill_pp_kernel(const PrefillParams p) {
     // V(i+1) replaces V(i-1), last read in C_PV(i-1), one cluster before the second group gets
     // here; its rows were requested in L_V(i-1)
     if (i + 1 < ntiles) {
-      write_rows(NPAR * 2 * kTileBytes + kTileBytes, vreg);
+      write_rows(IntC<kVOff + NPAR * kVStep>{}, vreg);
       __builtin_amdgcn_sched_barrier(0);
       load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
     }
     LV_STAMP(8)
     if constexpr (CUR) {
-      load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<0>{});
-      load_vg(vx[1], vbase, PAR * 2 * kTileBytes, IntC<1>{});
-      load_vg(vx[2], vbase, PAR * 2 * kTileBytes, IntC<2>{});
+      load_vg(vx[0], vbase, kVOff + PAR * kVStep, IntC<0>{});
+      load_vg(vx[1], vbase, kVOff + PAR * kVStep, IntC<1>{});
+      load_vg(vx[2], vbase, kVOff + PAR * kVStep, IntC<2>{});
     }
     LV_STAMP(9)
     mask_tile(i + 1, S[NPAR][0], S[NPAR][1]);
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(2)
-    if (!(LV_ABL & 256)) __syncthreads();
+    if (!(LV_ABL & 256)) wg_barrier();
     LV_STAMP(6)
     __builtin_amdgcn_sched_barrier(0);
     // ---- C_PV(i): O += V(i)^T P(i); in the MFMAs' shadow the first half of the softmax of tile
@@ -1062,7 +1230,7 @@ void prefill_pp_kernel(const PrefillParams p) {
       head(S[NPAR][0], S[NPAR][1]);
       if constexpr (CUR) mix4(IntC<6>{}, IntC<0>{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (CUR) { if (!(LV_ABL & 8192)) load_vg(vx[0], vbase, PAR * 2 * kTileBytes, IntC<3>{}); }
+      if constexpr (CUR) { if (!(LV_ABL & 8192)) load_vg(vx[0], vbase, kVOff + PAR * kVStep, IntC<3>{}); }
       if constexpr (CUR) pv4(vx[1], P[PAR], IntC<1>{});
       tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<0>{});
       tail_q(S[NPAR][0], P[NPAR][0], ps4, IntC<1>{});
@@ -1081,52 +1249,30 @@ void prefill_pp_kernel(const PrefillParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     LV_STAMP(3)
-    if (!(LV_ABL & 256)) __syncthreads();
+    if (!(LV_ABL & 256)) wg_barrier();
     LV_STAMP(7)
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue. The first K/V tiles are requested before Q, and Q comes in whole 256-byte rows
-  // by LDS-DMA (one wave instruction = 4 rows of the wave's own 32, so only the wave's own wait
-  // stands between the copy and its fragment reads): the three latencies overlap, and no lane
-  // gathers 32-byte pieces of 32 different rows.
-  load_rows(0, p.k, k_row_bytes, st_koff, kreg);
-  load_rows(0, p.v, v_row_bytes, st_voff, vreg);
-  {
-    const int lrow = lane >> 4;                                  // row inside a 4-row piece
-#pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
-      const int r = 4 * pc + lrow;                               // row of the wave's 32
-      const int lchunk = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
-      const int row_ld = min(wrow0 + r, Lq - 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(p.q + static_cast<int64_t>(q_start + row_ld) * p.q_stride0 +
-                                                          hq * kHeadDim + 8 * lchunk),
-          (__attribute__((address_space(3))) void*)(lds3 + kQImg + wave * 8192 + 1024 * pc), 16, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (ntiles > 0) write_rows(0, kreg);
-  __builtin_amdgcn_sched_barrier(0);
-  load_rows(1, p.k, k_row_bytes, st_koff, kreg);
-  {
+  // Q fragments out of the wave's Q image (landed and waited for by this wave)
+  auto read_q = [&]() {
     bf16x8 qtmp[8];
+    const int ln = fresh_lane();
+    const int cq = ln & 31;
+    const int kb = (256 * cq) | (16 * ((ln >> 5) ^ (((cq & 3) << 2) | ((cq >> 2) & 3))));    // = kbase0
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-      qtmp[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds3 + kQImg + wave * 8192 + (kbase0 ^ (32 * s)));
+      qtmp[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(lds3 + kQImg + wave * 8192 + (kb ^ (32 * s)));
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = static_cast<__bf16>(static_cast<float>(qtmp[s][j]) * q_pow);
       asm volatile("" ::"v"(qf[s]));   // retire the reads before the tile loop
     }
-  }
-  LV_TL(1)
-  if (ntiles > 0) {
+  };
+  // the tile loop of one query tile: K(0) (PERSIST: and K(1)) published, V(0) in vreg
+  auto tile_loop = [&]() {
     // K(0) published, K(1) and V(0) in flight (L_K(-1) publishes K(1), L_V(-1) V(0))
-    __syncthreads();
-    if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
-    LV_TL(2)
     LV_CLOCK_BEGIN
     body(-1, IntC<1>{}, IntC<0>{});
     // Every interval also forms the scores of tile i+1; past the last tile they are computed from
@@ -1137,16 +1283,12 @@ void prefill_pp_kernel(const PrefillParams p) {
       body(i, IntC<0>{}, IntC<1>{});
       if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{});
     }
-    if (grp == 0) __syncthreads();
+    if (grp == 0) wg_barrier();
     LV_CLOCK_END
-    LV_TL(3)
-  }
-  LV_STAMP_FLUSH
-
-  // ---- epilogue
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-  {
+  };
+  auto store_out = [&]() {
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     u32x2 w[16];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -1155,15 +1297,117 @@ void prefill_pp_kernel(const PrefillParams p) {
         w[4 * dt + rg][0] = pack_bf16x2(oacc[dt][4 * rg + 0] * inv, oacc[dt][4 * rg + 1] * inv);
         w[4 * dt + rg][1] = pack_bf16x2(oacc[dt][4 * rg + 2] * inv, oacc[dt][4 * rg + 3] * inv);
       }
-    uint16_t* ob = p.o + static_cast<int64_t>(q_start + min(my_row, Lq - 1)) * p.o_stride0 + hq * kHeadDim;
-    store_row_128(ob, h, my_row < Lq, w);
-  }
-  LV_TL(4)
+    const int ln = fresh_lane();
+    const int row = wave * 32 + (ln & 31);
+    uint16_t* ob = p.o + static_cast<int64_t>(qrow0 + min(row, nrows - 1)) * p.o_stride0 + hq * kHeadDim;
+    store_row_128(ob, ln >> 5, row < nrows, w);
+  };
+
+  if constexpr (!PERSIST) {
+    // ---- prologue. The first K/V tiles are requested before Q, and Q comes in whole 256-byte rows
+    // by LDS-DMA (one wave instruction = 4 rows of the wave's own 32, so only the wave's own wait
+    // stands between the copy and its fragment reads): the three latencies overlap, and no lane
+    // gathers 32-byte pieces of 32 different rows.
+    load_rows(0, p.k, k_row_bytes, st_koff, kreg);
+    load_rows(0, p.v, v_row_bytes, st_voff, vreg);
+    dma_q(qrow0, nrows);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ntiles > 0) write_k(IntC<kKOff>{}, kreg);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(1, p.k, k_row_bytes, st_koff, kreg);
+    read_q();
+    LV_TL(1)
+    if (ntiles > 0) {
+      __syncthreads();
+      if (grp == 1) __syncthreads();   // the second group runs one cluster behind the first
+      LV_TL(2)
+      tile_loop();
+      LV_TL(3)
+    }
+    LV_STAMP_FLUSH
+    store_out();
+    LV_TL(4)
 #ifdef LV_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave's queue
-  LV_TL(5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave's queue
+    LV_TL(5)
 #endif
-  LV_TL_FLUSH
+    LV_TL_FLUSH
+  } else {
+    // ---- cold start: this workgroup's first query tile arrives the way every later one does, only
+    // nothing is computed meanwhile
+    dma_q(qrow0, nrows);
+    if (Lk > 0) {
+      dma_k(tile_row(0), min(BN, Lk), kKOff);
+      dma_k(tile_row(Lk > BN ? 1 : 0), Lk > BN ? min(BN, Lk - BN) : min(BN, Lk), kKOff + kKStep);
+      load_rows_at(tile_row(0), min(BN, Lk), p.v, v_row_bytes, st_voff, vreg);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc counts from here
+    LV_TL(1)
+    LV_TLA_START      // diagnostic builds: tl_t[2] += seam (Q fragments, barrier), [3] += tile loop, [4] += wait + output stores
+    while (true) {
+      // entry of the table for the query tile after this one (nrows <= 0: none); a scalar load that
+      // lands while the first cluster of this tile runs
+      int n_qrow0 = 0, n_nrows = 0, n_lim0 = 0, n_kref = 0, n_Lk = 0;
+      if (it_k + 1 < it_depth) {
+        const table_ptr e = item_ptr(it_k + 1);
+        n_qrow0 = e[0]; n_nrows = e[1]; n_lim0 = e[2]; n_kref = e[3]; n_Lk = e[4];
+      }
+      read_q();
+      reset_state();
+      // the DMA'd K tiles of every wave are in LDS (each wave waited for its own after the last tile
+      // loop) and the old tile's LDS reads are over
+      wg_barrier();
+      if (ntiles > 0 && grp == 1) wg_barrier();   // the second group runs one cluster behind the first
+      LV_TLA(2)
+      load_rows(2, p.k, k_row_bytes, st_koff, kreg);   // K(0), K(1) are in LDS already; before the copies below, so
+                                                       // that the wait for K(2) does not wait for them as well
+      // ---- the tile after this one: Q rows into the image (this wave's fragments are in registers),
+      // first two K tiles into the other K slot pair. Without a next tile the same copies are made
+      // of this tile's own rows (into places nobody reads any more): the instruction stream, and with
+      // it the compiler's count of outstanding loads, is the same for every tile.
+      const bool more = n_nrows > 0;
+      {
+        const int f_qrow0 = more ? n_qrow0 : qrow0, f_nrows = more ? n_nrows : nrows;
+        const int f_kref = more ? n_kref : kref, f_Lk = more ? n_Lk : Lk;
+        const table_ptr f_bt = PAGED ? block_table + static_cast<int64_t>(f_kref) * p.bt_stride : nullptr;
+#ifndef LV_PABL
+#define LV_PABL 0     // diagnostic builds only: 1 = no copies for the next query tile (results then wrong)
+#endif
+        if (!(LV_PABL & 1)) dma_q(f_qrow0, f_nrows);
+        // (no branch around the copies: a conditional copy would leave hipcc unable to count the
+        // outstanding loads behind it, and its next wait would be for all of them)
+        const int other = kring ^ kRingB;
+        const bool second = f_Lk > BN;
+        if (!(LV_PABL & 1)) {
+          dma_k(f_Lk > 0 ? tile_row_of(f_bt, f_kref, 0) : 0, min(BN, f_Lk), other + kKOff);
+          dma_k(f_Lk > 0 ? tile_row_of(f_bt, f_kref, second ? 1 : 0) : 0, second ? min(BN, f_Lk - BN) : min(BN, f_Lk),
+                other + kKOff + kKStep);
+        }
+      }
+      if (ntiles > 0) tile_loop();
+      LV_TLA(3)
+      // every copy for the next tile has landed (they are older than every load of the loop, so this
+      // wait is short); its first V tile is requested before this tile's output is stored
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc counts from here
+      if (more && n_Lk > 0 && !(LV_PABL & 2)) {
+        const table_ptr n_bt = PAGED ? block_table + static_cast<int64_t>(n_kref) * p.bt_stride : nullptr;
+        load_rows_at(tile_row_of(n_bt, n_kref, 0), min(BN, n_Lk), p.v, v_row_bytes, st_voff, vreg);
+      }
+      store_out();
+      LV_TLA(4)
+      if (!more) break;
+      qrow0 = n_qrow0; nrows = n_nrows; lim0 = n_lim0; kref = n_kref; Lk = n_Lk;
+      derive();
+      if (!(LV_PX & 4)) kring ^= kRingB;
+      ++it_k;
+    }
+    LV_STAMP_FLUSH
+#ifdef LV_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc counts from here
+    LV_TL(5)
+#endif
+    LV_TL_FLUSH
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1736,8 +1980,14 @@ static void launch_w64(const PrefillParams& p, hipStream_t stream) {
 
 template <bool PAGED>
 static void launch_pp(const PrefillParams& p, hipStream_t stream) {
+  if (p.order_lanes > 0) {
+    // item table: one workgroup per (query head, table column, lane), each walking its lane's entries
+    const unsigned grid = static_cast<unsigned>(p.num_heads) * p.order_cols * p.order_lanes;
+    hipLaunchKernelGGL((prefill_pp_kernel<PAGED, true>), dim3(grid), dim3(512), 0, stream, p);
+    return;
+  }
   const int64_t total = grid_items(p, 256) * p.num_heads;
-  hipLaunchKernelGGL((prefill_pp_kernel<PAGED>), dim3(static_cast<unsigned>(total)), dim3(512), 0, stream, p);
+  hipLaunchKernelGGL((prefill_pp_kernel<PAGED, false>), dim3(static_cast<unsigned>(total)), dim3(512), 0, stream, p);
 }
 
 template <bool PAGED, int NW, int RB, bool DMA>
@@ -1774,6 +2024,11 @@ int prefill_order_columns(int num_kv_heads) {
   return (num_kv_heads == 1 || num_kv_heads == 2 || num_kv_heads == 4) ? 8 / num_kv_heads : 1;
 }
 
+int prefill_order_lanes(int num_heads, int num_kv_heads) {
+  const int per_lane = num_heads * prefill_order_columns(num_kv_heads);   // workgroups one lane adds to the grid
+  return per_lane >= 256 ? 1 : 256 / per_lane;                            // 256 compute units, one 512-thread workgroup each
+}
+
 int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   if (grid_items(p, 128) * p.num_heads * p.nsplit > INT32_MAX)
     return fail(LV_ERR_UNSUPPORTED, "prefill: grid too large");
@@ -1789,6 +2044,9 @@ int launch_prefill_attn(const PrefillParams& p, hipStream_t stream) {
   if (p.tile_order && p.order_rows != (cfg == 0 ? 128 : 256))
     return fail(LV_ERR_INVALID_ARGUMENT, "prefill: tile_order built for %d-row tiles, this launch uses %d-row tiles "
                 "(lv_prefill_tile_rows)", p.order_rows, cfg == 0 ? 128 : 256);
+  if (p.order_lanes > 0 && cfg != 2)
+    return fail(LV_ERR_INVALID_ARGUMENT, "prefill: an item table (tile_order_lanes > 0) is for the phase-locked kernel "
+                "(max_seqlen_q >= 2048 or LV_PREFILL_KERNEL_PP), one KV pass");
   if (cfg == 4) {
     if (p.block_table) launch_w64<true>(p, stream); else launch_w64<false>(p, stream);
   } else if (cfg == 2) {

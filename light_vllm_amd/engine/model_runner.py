@@ -320,12 +320,14 @@ class ModelRunner:
         cu_k_t = self._to_device(cu_k, torch.int32)
         slot_mapping = self._to_device(slot_mapping, torch.int32)
         # launch order of the query tiles for the prefill kernels: on a tensor-parallel shard with
-        # fewer than 8 kv heads it keeps each sequence's K/V stream on one or two XCDs (None otherwise)
+        # fewer than 8 kv heads it keeps each sequence's K/V stream on one or two XCDs; for long prompts
+        # on a grid larger than the chip, the balanced tile lists of the persistent kernel (None otherwise)
         tile_order = None
         if self.on_gpu and max_q > 0:
             hf = self.config.hf_config
             tile_order = ops.prefill_tile_order(lens_q, lens_k, hf.num_attention_heads // self.world_size,
-                                                hf.num_key_value_heads // self.world_size, self.device)
+                                                hf.num_key_value_heads // self.world_size, self.device,
+                                                paged=block_tables is not None)
         set_context(True, cu_q_t, cu_k_t, max_q, max_k, slot_mapping, None, block_tables, tile_order=tile_order)
         return input_ids, positions
 

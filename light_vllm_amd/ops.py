@@ -18,10 +18,13 @@ PREFILL_KERNELS = {"auto": 0, "w4": 1, "w8": 2, "pp": 3, "w64": 5, "w4_dma": 1 |
 # kernels by setting these; "valu" applies where that kernel exists, group sizes 1, 2, 4, 8).
 DEFAULT_KERNEL = {"decode": "auto", "prefill": "auto"}
 STATS = {"tile_order_dropped": 0}
+_PERSISTENT_PREFILL = False     # prefill_tile_order(persistent=None) plans item tables for the persistent long-prompt
+                                # kernel only when this is set: parity-green, but not faster yet (see prefill_tile_order)
 
 
 def prefill_tile_order(lens_q, lens_k, num_heads: int, num_kv_heads: int, device,
-                       num_splits: int = 0, kernel: Optional[str] = None, force: bool = False):
+                       num_splits: int = 0, kernel: Optional[str] = None, force: bool = False,
+                       paged: bool = False, persistent: Optional[bool] = None):
     """Launch order of the query tiles for a prefill call on sequences of lens_q new rows over lens_k
     keys (python ints; the caller of the reference's flash_attn_varlen_func has them when it builds
     cu_seqlens, lightvllm/engine/model_runner.py:325-328), as a prefill_order.TileOrder on `device`
@@ -31,15 +34,36 @@ def prefill_tile_order(lens_q, lens_k, num_heads: int, num_kv_heads: int, device
     (4 x 4096 tokens, 8q/1kv: 0.192 -> 0.147 ms; 16 x 1024, 4q/1kv: 0.039 -> 0.032 ms), and a launch
     that would put at most one 256-row workgroup on a CU is planned on 128-row tiles instead, so
     that every CU gets a heavy and a light tile (4 x 4096, 4q/1kv: 0.107 -> 0.099 ms).
+    persistent=True (or the module switch _PERSISTENT_PREFILL with persistent=None): when the launch runs
+    the long-prompt kernel in one KV pass (max_seqlen_q >= 2048, or kernel "pp") the result is an ITEM
+    table for that kernel's persistent form instead (whatever the head count): one workgroup per compute
+    unit walks a host-balanced list of tiles, the next tile's Q rows and first K/V tiles arriving while
+    the current one is computed. Bit-identical results; measured on 4 x 4096 tokens, 32q/8kv: what a
+    workgroup pays per tile outside its tile loop falls from 7.6 us to 2.5 us, but the tile loop itself
+    runs 3-10 % longer and the static lists end 30 us apart, so the launch is 2-3 % SLOWER than one
+    tile per workgroup: off by default. paged: the launch reads K/V through a block table (the table's K
+    references are then sequence indices).
     force: build a table whatever the head count (tests)."""
-    from .prefill_order import build_tile_order, order_columns
+    from .prefill_order import build_item_table, build_tile_order, order_columns
     lens_q, lens_k = [int(x) for x in lens_q], [int(x) for x in lens_k]
-    if not lens_q or max(lens_q) <= 0 or (order_columns(num_kv_heads) == 1 and not force):
+    if not lens_q or max(lens_q) <= 0:
         return None
     lib = _lib.load()
     max_q, max_k = max(lens_q), max(lens_k)
     nsplit = num_splits if num_splits > 0 else lib.lv_prefill_num_splits(len(lens_q), max_q, max_k, num_heads)
     name = kernel or DEFAULT_KERNEL["prefill"]
+    runs_pp = nsplit == 1 and (name == "pp" or (name == "auto" and max_q >= 2048))
+    if persistent is None:
+        tiles = sum(-(-lq // 256) for lq in lens_q) * num_heads
+        persistent = runs_pp and tiles > 256 and _PERSISTENT_PREFILL
+    if persistent and runs_pp:
+        order = build_item_table(lens_q, lens_k, max_q, 256, num_heads, num_kv_heads, paged)
+        if order is None:
+            return None
+        order.num_splits = 1
+        return order.to(device)
+    if order_columns(num_kv_heads) == 1 and not force:
+        return None
     if name == "auto" and nsplit == 1:
         wgs256 = sum(-(-lq // 256) for lq in lens_q) * num_heads
         if 128 < wgs256 <= 256 and lib.lv_prefill_tile_rows(max_q, 1, 0) == 256:
@@ -158,14 +182,20 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     if tile_order is not None and tile_order.kernel and kernel is None and name == "auto":
         name = tile_order.kernel        # the table was planned on another tile height than the default kernel's
     hint = PREFILL_KERNELS[name]
-    to_ptr, to_len, to_rows = None, 0, 0
+    to_ptr, to_len, to_rows, to_lanes = None, 0, 0, 0
     if tile_order is not None:
-        if (tile_order.tile_rows == lib.lv_prefill_tile_rows(int(max_seqlen_q), nsplit, hint)
+        lanes = getattr(tile_order, "lanes", 0)
+        fits = (tile_order.tile_rows == lib.lv_prefill_tile_rows(int(max_seqlen_q), nsplit, hint)
                 and tile_order.max_seqlen_q == int(max_seqlen_q)
-                and tile_order.cols == lib.lv_prefill_order_columns(Hkv)):
+                and tile_order.cols == lib.lv_prefill_order_columns(Hkv))
+        if lanes:       # an item table: the phase-locked kernel in one pass, the same addressing mode it was built for
+            pp = (hint & 0xff) == PREFILL_KERNELS["pp"] or ((hint & 0xff) == 0 and int(max_seqlen_q) >= 2048)
+            fits = (fits and nsplit == 1 and pp and lanes == lib.lv_prefill_order_lanes(Hq, Hkv)
+                    and bool(tile_order.paged) == (block_table is not None))
+        if fits:
             tab = tile_order.table
             assert tab.dtype == torch.int32 and tab.is_contiguous() and tab.device == q.device
-            to_ptr, to_len, to_rows = tab.data_ptr(), tab.numel(), tile_order.tile_rows
+            to_ptr, to_len, to_rows, to_lanes = tab.data_ptr(), tab.numel(), tile_order.tile_rows, lanes
         else:
             STATS["tile_order_dropped"] += 1
     with torch.cuda.device(dev):
@@ -174,7 +204,7 @@ def prefill_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                                  cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), B,
                                  int(max_seqlen_q), int(max_seqlen_k), bt_ptr, bt_stride, block_size,
                                  Hq, Hkv, D, float(softmax_scale), total_q, ws_ptr, ws_bytes, nsplit,
-                                 to_ptr, to_len, to_rows, hint, _stream_ptr(dev))
+                                 to_ptr, to_len, to_rows, to_lanes, hint, _stream_ptr(dev))
     del keep
     _lib.check(rc, "lv_prefill_attn")
     return out

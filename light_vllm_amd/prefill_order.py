@@ -27,7 +27,8 @@ KEY_TILE = 64            # keys per K/V tile of the prefill kernels
 
 @dataclass
 class TileOrder:
-    """table: flat [rows * cols] list (or device tensor) of b * qtiles + t, -1 = empty place.
+    """table: flat [rows * cols] list (or device tensor) of b * qtiles + t, -1 = empty place; with
+    lanes > 0 an item table, flat [depth * lanes * cols * 8] (build_item_table).
     kernel / num_splits: what the table was planned for (None / 0: the library's own choice)."""
     table: object
     tile_rows: int
@@ -35,13 +36,15 @@ class TileOrder:
     max_seqlen_q: int
     kernel: Optional[str] = None
     num_splits: int = 0
+    lanes: int = 0
+    paged: bool = False      # item tables only: K references are sequence indices (block-table rows)
 
     def to(self, device):
         import torch
         t = torch.tensor(self.table, dtype=torch.int32, device="cpu")
         if torch.device(device).type != "cpu":
             t = t.pin_memory().to(device, non_blocking=True)
-        return TileOrder(t, self.tile_rows, self.cols, self.max_seqlen_q, self.kernel, self.num_splits)
+        return TileOrder(t, self.tile_rows, self.cols, self.max_seqlen_q, self.kernel, self.num_splits, self.lanes, self.paged)
 
 
 def tile_weight(lq: int, lk: int, t: int, tile_rows: int) -> int:
@@ -101,3 +104,74 @@ def build_tile_order(lens_q: Sequence[int], lens_k: Sequence[int], max_seqlen_q:
         for r, (_, code) in enumerate(col):
             table[r * cols + c] = code
     return TileOrder(table, tile_rows, cols, max_seqlen_q)
+
+
+def order_lanes(num_heads: int, num_kv_heads: int) -> int:
+    """lv_prefill_order_lanes: lists per (query head, column) of an item table."""
+    per_lane = num_heads * order_columns(num_kv_heads)
+    return 1 if per_lane >= 256 else 256 // per_lane
+
+
+def build_item_table(lens_q: Sequence[int], lens_k: Sequence[int], max_seqlen_q: int, tile_rows: int,
+                     num_heads: int, num_kv_heads: int, paged: bool) -> Optional[TileOrder]:
+    """Item table for the persistent long-prompt kernel (lv_prefill_attn, tile_order_lanes > 0): the
+    query tiles of sequences of lens_q new rows over lens_k keys, dealt to `lanes` lists per table
+    column so that every list carries about the same number of key tiles (longest processing time
+    first: heaviest tile to the list that is lightest so far), each list heaviest first. A sequence's
+    tiles stay inside one or two columns as in build_tile_order (one XCD's L2 per K/V stream). An entry
+    is {first q row, valid rows, causal limit of the first row, K reference, keys, 0, 0, 0}, the K
+    reference being the sequence's first packed K/V row, or its index when K/V are paged. None when
+    there is no tile."""
+    cols = order_columns(num_kv_heads)
+    lanes = order_lanes(num_heads, num_kv_heads)
+    assert len(lens_q) == len(lens_k) and tile_rows > 0
+    q_start = k_start = 0
+    seqs = []        # (total weight, [(weight, entry)])
+    for b, (lq, lk) in enumerate(zip(lens_q, lens_k)):
+        assert 0 <= lq <= max_seqlen_q
+        items = []
+        for t in range(-(-lq // tile_rows) - 1, -1, -1):
+            q0 = t * tile_rows
+            entry = [q_start + q0, min(tile_rows, lq - q0), q0 + lk - lq, b if paged else k_start, lk, 0, 0, 0]
+            items.append((tile_weight(lq, lk, t, tile_rows), entry))
+        if items:
+            seqs.append((sum(w for w, _ in items), items))
+        q_start += lq
+        k_start += lk
+    if not seqs:
+        return None
+    seqs.sort(key=lambda s: -s[0])
+    stream = []
+    for _, items in seqs:       # heavy and light tiles of a sequence alternate: any piece carries its mean weight
+        lo, hi = 0, len(items) - 1
+        while lo <= hi:
+            stream.append(items[lo])
+            if hi != lo:
+                stream.append(items[hi])
+            lo, hi = lo + 1, hi - 1
+    total = sum(w for w, _ in stream)
+    columns: List[List] = [[] for _ in range(cols)]
+    cum = 0
+    for w, entry in stream:
+        c = 0 if cols == 1 else min(cols - 1, int((cum + w / 2) * cols / max(total, 1)))
+        columns[c].append((w, entry))
+        cum += w
+    lists = []       # [col][lane] -> entries
+    for col in columns:
+        col.sort(key=lambda it: -it[0])
+        load = [0] * lanes
+        mine: List[List] = [[] for _ in range(lanes)]
+        for w, entry in col:
+            r = min(range(lanes), key=lambda j: (load[j], j))
+            mine[r].append(entry)
+            load[r] += max(w, 1)
+        lists.append(mine)
+    depth = max(len(lst) for col in lists for lst in col)
+    empty = [0] * 8
+    table: List[int] = []
+    for k in range(depth):
+        for r in range(lanes):
+            for c in range(cols):
+                lst = lists[c][r]
+                table += lst[k] if k < len(lst) else empty
+    return TileOrder(table, tile_rows, cols, max_seqlen_q, lanes=lanes, paged=paged)

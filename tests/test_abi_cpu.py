@@ -21,7 +21,7 @@ def test_header_declares_the_expected_entry_points():
         "lv_qk_norm_rope_store", "lv_add_rms_norm", "lv_silu_and_mul",
         "lv_decode_num_splits", "lv_decode_workspace_bytes", "lv_decode_attn", "lv_decode_attn_static",
         "lv_decode_attn_planned", "lv_prefill_max_workspace_bytes",
-        "lv_prefill_num_splits", "lv_prefill_workspace_bytes", "lv_prefill_tile_rows", "lv_prefill_order_columns",
+        "lv_prefill_num_splits", "lv_prefill_workspace_bytes", "lv_prefill_tile_rows", "lv_prefill_order_columns", "lv_prefill_order_lanes",
         "lv_comm_create", "lv_comm_get_handle", "lv_comm_connect", "lv_comm_all_reduce", "lv_comm_failed",
         "lv_comm_destroy", "lv_comm_all_reduce_add_rms_norm", "lv_comm_set_one_shot_inflow", "lv_comm_one_shot_inflow"])
 
@@ -106,10 +106,10 @@ def test_argument_validation_happens_before_any_launch():
     rc = lib.lv_store_kvcache(p16, p16, 512, 1024, p16, p16, p16, 1, 8, 128, 256, None)
     assert rc == -1
     # heads not divisible
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 8, None, 0, 1, None, 0, 0, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 12, 8, 128, 0.1, 8, None, 0, 1, None, 0, 0, 0, 0, None)
     assert rc == -1
     # scale must be finite and positive (a zero scale would turn the pre-scaled prefill kernel's constants into NaN)
-    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 8, None, 0, 1, None, 0, 0, 0, None)
+    rc = lib.lv_prefill_attn(p16, p16, p16, p16, 1024, 1024, 1024, 1024, p16, p16, 1, 8, 8, None, 0, 0, 8, 8, 128, 0.0, 8, None, 0, 1, None, 0, 0, 0, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()
     rc = lib.lv_decode_attn(p16, p16, p16, p16, 1024, 1024, p16, p16, 4, 1, 4, 256, 8, 8, 128, float("nan"), None, 0, 1, None, 0, None)
     assert rc == -1 and b"scale" in lib.lv_last_error()

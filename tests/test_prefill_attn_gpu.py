@@ -269,12 +269,12 @@ def test_prefill_tile_order_for_other_tile_height_is_rejected_by_the_abi(gpu):
     rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
                              v.stride(0), out.stride(0), d["cu_q"].data_ptr(), d["cu_k"].data_ptr(), 2, 300, 300,
                              None, 0, 0, 8, 1, 128, float(d["scale"]), q.size(0), None, 0, 1,
-                             wrong.table.data_ptr(), wrong.table.numel(), wrong.tile_rows, hint, None)
+                             wrong.table.data_ptr(), wrong.table.numel(), wrong.tile_rows, 0, hint, None)
     assert rc == -1 and b"tile_order" in lib.lv_last_error()
     rc = lib.lv_prefill_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(0), k.stride(0),
                              v.stride(0), out.stride(0), d["cu_q"].data_ptr(), d["cu_k"].data_ptr(), 2, 300, 300,
                              None, 0, 0, 8, 1, 128, float(d["scale"]), q.size(0), None, 0, 1,
-                             wrong.table.data_ptr(), 7, rows, hint, None)
+                             wrong.table.data_ptr(), 7, rows, 0, hint, None)
     assert rc == -1 and b"tile_order_len" in lib.lv_last_error()
 
 

@@ -62,3 +62,52 @@ def test_bottom_right_alignment_of_weights():
     assert tile_weight(100, 4196, 0, 128) == (4196 - 1) // 64 + 1
     # packed: tile t of 128 rows sees keys up to its last row
     assert tile_weight(1000, 1000, 0, 128) == 2 and tile_weight(1000, 1000, 7, 128) == 16
+
+
+def test_item_table_covers_every_tile_once_and_balances_lanes():
+    """Item tables of the persistent long-prompt kernel: every query tile of every sequence appears in
+    exactly one list with the values cu_seqlens imply, lists are contiguous from depth 0, heaviest
+    first, and carry near-equal numbers of key tiles."""
+    from light_vllm_amd.prefill_order import build_item_table, order_columns, order_lanes, tile_weight
+    for lens_q, lens_k, Hq, Hkv, paged in (([4096] * 4, [4096] * 4, 32, 8, False),
+                                           ([4096, 3000, 1024, 8264], [4096, 3000, 1024, 8264], 32, 8, False),
+                                           ([1976, 256, 700, 2088], [3000, 2304, 700, 2600], 8, 1, True),
+                                           ([300, 1], [300, 1], 4, 1, False)):
+        order = build_item_table(lens_q, lens_k, max(lens_q), 256, Hq, Hkv, paged)
+        cols, lanes = order_columns(Hkv), order_lanes(Hq, Hkv)
+        assert order.cols == cols and order.lanes == lanes and order.paged == paged
+        assert lanes == max(1, 256 // (Hq * cols))
+        tab = order.table
+        assert len(tab) % (8 * cols * lanes) == 0
+        depth = len(tab) // (8 * cols * lanes)
+        cu_q = [0]
+        cu_k = [0]
+        for a, b in zip(lens_q, lens_k):
+            cu_q.append(cu_q[-1] + a)
+            cu_k.append(cu_k[-1] + b)
+        seen, loads = set(), []
+        for c in range(cols):
+            for r in range(lanes):
+                ended, load, last_w = False, 0, None
+                for k in range(depth):
+                    e = tab[((k * lanes + r) * cols + c) * 8:][:8]
+                    if e[1] <= 0:
+                        ended = True
+                        continue
+                    assert not ended, "a list must be contiguous from depth 0"
+                    qrow0, nrows, lim0, kref, lk = e[:5]
+                    b = next(i for i in range(len(lens_q)) if cu_q[i] <= qrow0 < cu_q[i + 1])
+                    q0 = qrow0 - cu_q[b]
+                    assert q0 % 256 == 0 and nrows == min(256, lens_q[b] - q0)
+                    assert lim0 == q0 + lens_k[b] - lens_q[b] and lk == lens_k[b]
+                    assert kref == (b if paged else cu_k[b])
+                    assert (b, q0) not in seen
+                    seen.add((b, q0))
+                    w = tile_weight(lens_q[b], lens_k[b], q0 // 256, 256)
+                    assert last_w is None or w <= last_w, "heaviest first inside a list"
+                    last_w = w
+                    load += w
+                loads.append(load)
+        assert len(seen) == sum(-(-n // 256) for n in lens_q)
+        if cols == 1 and len(seen) >= 4 * lanes:
+            assert max(loads) - min(loads) <= 64 + max(loads) // 10      # longest-processing-time-first keeps the lists close

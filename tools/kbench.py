@@ -220,6 +220,16 @@ def main():
         for kernel in ("pp", "w8", "w64"):
             for L in (2048, 4096, 8192, 16384):
                 rows.append(prefill_case([L] * (16384 // L), 32, 8, kernel=kernel))
+    if args.what == "prefill_persist1":
+        for order in (None, "desc", None, "desc"):
+            rows.append(prefill_case([4096] * 4, 32, 8, order=order))
+        for order in (None, "desc"):
+            rows.append(prefill_case([8192] * 2, 32, 8, order=order))
+    if args.what == "prefill_persist":   # one query tile per workgroup against the persistent form (item tables)
+        for lens, Hq, Hkv in (([4096] * 4, 32, 8), ([2048] * 8, 32, 8), ([8192] * 2, 32, 8), ([4096, 3000, 1024, 8264], 32, 8),
+                              ([4096] * 4, 8, 1), ([4096] * 4, 16, 4)):
+            for order in (None, "desc", None, "desc"):
+                rows.append(prefill_case(lens, Hq, Hkv, order=order))
     if args.what == "prefill_tp8":       # one rank's share of a 4 x 4096 prefill at TP = 8: kernels x KV runs
         ops.reserve_decode_workspace(dev, 1 << 30)
         for Hq, Hkv in ((8, 1), (4, 1)):
@@ -389,7 +399,8 @@ def main():
         nbytes = N * D * 2 * (2 * Hq + 2 * Hkv + Hkv + 2 * Hkv)
         rows.append(dict(kind="qk_norm_rope_store", N=N, Hq=Hq, Hkv=Hkv, us=round(t * 1e6, 1), GBs=round(nbytes / t / 1e9, 1)))
     if args.what == "decode_b1":         # one long sequence: split pass vs merge pass (profile this one)
-        rows.append(decode_case(1, 32768, int(os.environ.get("KB_HQ", "4")), int(os.environ.get("KB_HKV", "1")), graph=True))
+        rows.append(decode_case(1, 32768, int(os.environ.get("KB_HQ", "4")), int(os.environ.get("KB_HKV", "1")),
+                                nsplit=int(os.environ.get("KB_NS", "0")), graph=True))
     if args.what == "decode_mid":        # launches around the point where splitting stops paying
         for (B, ctx, Hq, Hkv) in [(64, 4096, 32, 8), (32, 4096, 32, 8), (16, 4096, 32, 8), (128, 4096, 4, 1), (64, 32768, 16, 4)]:
             for ns in (0, 1, 2, 4):

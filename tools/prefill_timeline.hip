@@ -2,7 +2,7 @@
 // unit - prologue (Q fragments, first K/V tiles), tile loop, epilogue (output stores), and the gap until
 // the next workgroup starts on the same compute unit. Build and run:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DLV_TIMELINE -Iinclude -Ilight_vllm_amd/csrc \
-//         tools/prefill_timeline.hip -o tools/prefill_timeline && tools/prefill_timeline [seqlen [heads kv_heads]]
+//         tools/prefill_timeline.hip -o tools/prefill_timeline && tools/prefill_timeline [seqlen [heads kv_heads [persistent]]]
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -58,6 +58,38 @@ int main(int argc, char** argv) {
   p.batch = B; p.max_seqlen_q = L; p.num_heads = Hq; p.num_kv_heads = Hkv;
   p.kernel_hint = LV_PREFILL_KERNEL_PP;
   p.nsplit = 1; p.ws_o = nullptr; p.ws_ml = nullptr; p.total_q = (int64_t)B * L;
+  p.tile_order = nullptr; p.order_cols = 1; p.order_len = 0; p.order_rows = 0; p.order_lanes = 0;
+  const bool persistent = argc > 4 && atoi(argv[4]) != 0;
+  size_t n_slots = nwg;
+  if (persistent) {
+    // item table as prefill_order.build_item_table makes it for equal lengths: tiles dealt heaviest
+    // first to the lightest lane (8 kv heads: one column)
+    const int cols = lv::prefill_order_columns(Hkv), lanes = lv::prefill_order_lanes(Hq, Hkv);
+    if (cols != 1) { printf("persistent timeline: 8 kv heads only\n"); return 1; }
+    std::vector<std::vector<int>> lane_items(lanes);
+    std::vector<long> load(lanes, 0);
+    for (int t = qtiles - 1; t >= 0; --t)
+      for (int b = 0; b < B; ++b) {
+        int best = 0;
+        for (int r = 1; r < lanes; ++r) if (load[r] < load[best]) best = r;
+        lane_items[best].push_back(b * qtiles + t);
+        load[best] += (t + 1) * 4;
+      }
+    size_t depth = 0;
+    for (auto& v : lane_items) depth = std::max(depth, v.size());
+    std::vector<int> table(depth * lanes * 8, 0);
+    for (int r = 0; r < lanes; ++r)
+      for (size_t k = 0; k < lane_items[r].size(); ++k) {
+        const int b = lane_items[r][k] / qtiles, t = lane_items[r][k] % qtiles;
+        int* e = &table[(k * lanes + r) * 8];
+        e[0] = b * L + t * 256; e[1] = std::min(256, L - t * 256); e[2] = t * 256; e[3] = b * L; e[4] = L;
+      }
+    int* dtab; CK(hipMalloc(&dtab, table.size() * 4));
+    CK(hipMemcpy(dtab, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    p.tile_order = dtab; p.order_len = (int64_t)table.size(); p.order_rows = 256; p.order_lanes = lanes;
+    n_slots = (size_t)Hq * lanes;
+    printf("persistent: %d lanes x %zu tiles each, %zu workgroups\n", lanes, depth, n_slots);
+  }
   p.scale_log2e = 0.08838834764f * 1.4426950408889634f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> times;
@@ -72,7 +104,23 @@ int main(int argc, char** argv) {
   std::sort(times.begin(), times.end());
   printf("30 launches: min %.3f ms, median %.3f ms, last %.3f ms\n", times[0], times[15], last_ms);
   std::vector<unsigned long long> tl(nwg * 8);
-  CK(hipMemcpy(tl.data(), dtl, nwg * 64, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(tl.data(), dtl, nwg * 64, hipMemcpyDeviceToHost));   // persistent launches fill the first n_slots entries
+  if (persistent) {
+    // per workgroup: [0] entry, [1] first tile arrived, [2] sum of seams, [3] sum of tile loops, [4] sum of
+    // (wait for the copies + output stores), [5] end (100 MHz ticks)
+    double seam = 0, loop = 0, fin = 0, cold = 0, life = 0; unsigned long long t0 = ~0ull, t1 = 0, first_end = ~0ull;
+    for (size_t w = 0; w < n_slots; ++w) {
+      const unsigned long long* d = &tl[w * 8];
+      cold += (double)(d[1] - d[0]); seam += (double)d[2]; loop += (double)d[3]; fin += (double)d[4]; life += (double)(d[5] - d[0]);
+      t0 = std::min(t0, d[0]); t1 = std::max(t1, d[5]); first_end = std::min(first_end, d[5]);
+    }
+    const double n = (double)n_slots, span = (double)(t1 - t0);
+    printf("launch spans %.1f us; per workgroup: life %.1f us (first to end %.1f us before the last), cold start %.2f us,\n"
+           "  seams %.2f us, tile loops %.2f us, copy wait + output stores %.2f us  (%.2f / %.2f / %.2f %% of the span)\n",
+           span / 100, life / n / 100, (t1 - first_end) / 100.0, cold / n / 100, seam / n / 100, loop / n / 100, fin / n / 100,
+           100 * seam / n / span, 100 * loop / n / span, 100 * fin / n / span);
+    return 0;
+  }
   // group the last launch's workgroups by compute unit, order by entry time
   std::map<unsigned long long, std::vector<size_t>> by_cu;
   unsigned long long tmin = ~0ull, tmax = 0;
