@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/decode_b1_ablation.log
 cd /tmp
 for NS in 32 64 128 256 512; do
   rm -rf /tmp/b1_$NS
-  KB_NS=$NS timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/b1_$NS -o b1 -- python3 $R/tools/kbench.py --what decode_b1 > /tmp/b1_$NS.log 2>&1 || { echo "ns=$NS failed" >> $OUT; tail -3 /tmp/b1_$NS.log >> $OUT; continue; }
+  KB_NS=$NS timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/b1_$NS -o b1 -- python3 $R/tools/kbench.py --what decode_b1 > /tmp/b1_$NS.log 2>&1 || { echo "ns=$NS failed" >> $OUT; tail -3 /tmp/b1_$NS.log >> $OUT; cat $OUT; exit 1; }
   python3 - $NS /tmp/b1_$NS /tmp/b1_$NS.log >> $OUT <<'PY'
 import csv, glob, json, sys
 ns, d, log = sys.argv[1], sys.argv[2], sys.argv[3]

@@ -153,6 +153,32 @@ def prefill_case(lens, Hq, Hkv, paged_prefix=0, data="normal", iters=50, kernel=
                 ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1), pct_peak=round(flops / t / 2.5e15 * 100, 1))
 
 
+def sdpa_case(B, L, Hq, Hkv, iters=50):
+    """The platform library on the same job, for scale only (nothing here ships it): torch's
+    scaled_dot_product_attention, causal, B equal prompts of L tokens, kv heads shared by enable_gqa."""
+    import torch.nn.functional as F
+    q = torch.randn(B, Hq, L, D, device=dev).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, L, D, device=dev).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, L, D, device=dev).to(torch.bfloat16)
+    out = {}
+    for name, backend in (("flash", torch.nn.attention.SDPBackend.FLASH_ATTENTION),
+                          ("efficient", torch.nn.attention.SDPBackend.EFFICIENT_ATTENTION)):
+        def fn():
+            with torch.nn.attention.sdpa_kernel(backend):
+                return F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=(Hq != Hkv))
+        try:
+            for _ in range(25):
+                fn()
+            torch.cuda.synchronize()
+            t = timeit(fn, iters=iters, warmup=2)
+        except Exception as e:  # noqa: BLE001 - a backend the build lacks is a result, not a failure
+            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:120]}"
+            continue
+        flops = B * 4 * Hq * D * (L * L - L * (L - 1) // 2)
+        out[name] = dict(ms=round(t * 1e3, 3), TFLOPs=round(flops / t / 1e12, 1))
+    return dict(kind="torch_sdpa", B=B, L=L, Hq=Hq, Hkv=Hkv, backends=out)
+
+
 def prefix_case(B, new, cached, Hq, Hkv, nsplit):
     """Prefix-cached prefill: `new` query tokens per sequence on top of `cached` tokens in the paged
     cache (Lk = cached + new), nsplit KV runs per query tile (0 = library heuristic, 1 = one pass)."""
@@ -208,6 +234,10 @@ def main():
         rows.append(prefill_case([4096, 3000, 1024, 8264], 32, 8))
         rows.append(prefill_case([1024] * 16, 16, 8))
         rows.append(prefill_case([4096] * 4, 8, 1))
+    if args.what == "prefill_sdpa":      # this library beside torch's own attention on the bench's prefill jobs
+        for (Hq, Hkv) in ((32, 8), (8, 1)):
+            rows.append(prefill_case([4096] * 4, Hq, Hkv))
+            rows.append(sdpa_case(4, 4096, Hq, Hkv))
     if args.what == "prefill_data":      # same launch, different operand values and burst lengths
         for data in ("normal", "uniform", "zeros"):
             for iters in (10, 100):
@@ -333,6 +363,9 @@ def main():
         for graph in (False, True):
             for ns in (0, 1, 2, 4, 8):
                 rows.append(decode_case(64, 32768, 8, 1, nsplit=ns, graph=graph))
+    if args.what == "decode_c4_tp":      # BASELINE config 4 (batch 32, 32k context) per rank at TP = 1, 2, 4, 8
+        for (Hq, Hkv) in [(32, 8), (16, 4), (8, 2), (4, 1)]:
+            rows.append(decode_case(32, 32768, Hq, Hkv, graph=True))
     if args.what == "decode_g8":
         rows.append(decode_case(256, 1024, 64, 8))
     if args.what == "decode_ragged1":    # ragged batches, one pass, graph replay: for comparing builds

@@ -65,8 +65,12 @@ def main():
         # one count = 512 bf16 multiply-accumulate FLOP issued on the matrix pipe
         d["mfma_flops_from_mops_counter"] = m["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
         d["mfma_flops_over_algorithmic"] = round(m["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / FLOPS, 3)
+    import hashlib
+    d["kernel_source_sha16"] = hashlib.sha256(open(os.path.join(ROOT, "light_vllm_amd", "csrc", "prefill_attn.hip"), "rb").read()).hexdigest()[:16]
     dst = os.path.join(ROOT, "profiles", f"{tag}_prefill_pmc_{short}")
     json.dump(d, open(dst + ".json", "w"), indent=1)
+    if "pp_kernel" in kernel:      # the default long-prompt kernel: what bench.py's prefill.rocprof shows
+        json.dump(d, open(os.path.join(ROOT, "profiles", "prefill_counters.json"), "w"), indent=1)
     with open(dst + ".csv", "w") as f:
         w = csv.writer(f)
         w.writerow(["Kernel_Name", "Counter_Name", "Mean_Per_Launch"])
