@@ -17,7 +17,7 @@ PREFILL_KERNELS = {"auto": 0, "w4": 1, "w8": 2, "pp": 3, "w64": 5, "w4_dma": 1 |
 # Process-wide default for calls that do not name a kernel (the parity tests iterate over the
 # kernels by setting these; "valu" applies where that kernel exists, group sizes 1, 2, 4, 8).
 DEFAULT_KERNEL = {"decode": "auto", "prefill": "auto"}
-STATS = {"tile_order_dropped": 0}
+STATS = {"tile_order_dropped": 0, "workspace_allocations": 0}
 _PERSISTENT_PREFILL = False     # prefill_tile_order(persistent=None) plans item tables for the persistent long-prompt
                                 # kernel only when this is set: parity-green, but not faster yet (see prefill_tile_order)
 
@@ -238,6 +238,7 @@ def reserve_decode_workspace(device: torch.device, nbytes: int) -> None:
         if cur is not None:
             _RETIRED.append(cur)
         _WORKSPACE[idx] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=f"cuda:{idx}")
+        STATS["workspace_allocations"] += 1     # a runner that reserved once sees this stay put
 
 
 def _workspace(device: torch.device, nbytes: int) -> Tuple[Optional[int], int, Optional[torch.Tensor]]:

@@ -28,7 +28,14 @@ def _drive(prompt_groups, eager, heads):
     hf = gqa4_config(2) if heads == "32q/8kv" else g8_config(2)
     cfg = Config(None, hf_config=hf, num_kvcache_blocks=300, max_num_seqs=4, max_model_len=33024,
                  max_num_batched_tokens=33024, enforce_eager=eager, random_seed=5)
+    from light_vllm_amd import _lib, ops
     runner, sch = ModelRunner(cfg, 0, []), Scheduler(cfg)
+    # the runner reserved its split-KV workspace before it sized the cache: enough for the 200-row
+    # prefill on 31 744 cached tokens (8 or 32 KV runs), and nothing allocates while serving
+    allocations = ops.STATS["workspace_allocations"]
+    hq = hf.num_attention_heads
+    assert runner.workspace_bytes >= _lib.load().lv_prefill_workspace_bytes(
+        200, hq, 128, _lib.load().lv_prefill_num_splits(1, 200, SHARED_BLOCKS * BLOCK + 200, hq))
     sp = SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True)
     out, cached = [], []
     for prompts, forced in prompt_groups:
@@ -48,6 +55,7 @@ def _drive(prompt_groups, eager, heads):
             sch.postprocess(batch, toks)
             step += 1
         out.append(steps)
+    assert ops.STATS["workspace_allocations"] == allocations, "the workspace grew while serving"
     runner.exit()
     return out, cached
 
