@@ -324,6 +324,33 @@ def main():
                               ([4096] * 4, 32, 8), ([1024] * 16, 4, 1), ([8192] * 2, 8, 1)):
             for order in (None, "desc"):
                 rows.append(prefill_case(lens, Hq, Hkv, order=order))
+    if args.what == "prefill_l2order":   # 8 kv heads: which sequences an XCD works on at the same time (L2 working set)
+        from light_vllm_amd.prefill_order import TileOrder
+        lens, qt = [4096] * 4, 16
+        tables = {
+            "library": None,
+            "heaviest tile of every sequence first": [b * qt + t for t in range(qt - 1, -1, -1) for b in range(4)],
+            "one sequence after another": [b * qt + t for b in range(4) for t in range(qt - 1, -1, -1)],
+            "two sequences at a time": [b * qt + t for pair in ((0, 1), (2, 3)) for t in range(qt - 1, -1, -1) for b in pair],
+        }
+        for name, codes in tables.items():
+            for _ in range(2):
+                r = prefill_case(lens, 32, 8)
+                if codes is not None:
+                    order = TileOrder(codes, 256, 1, 4096).to(dev)
+                    q = torch.randn(sum(lens), 32, D, device=dev).to(torch.bfloat16)
+                    k = torch.randn(sum(lens), 8, D, device=dev).to(torch.bfloat16)
+                    v = torch.randn(sum(lens), 8, D, device=dev).to(torch.bfloat16)
+                    cu = torch.tensor([0, 4096, 8192, 12288, 16384], dtype=torch.int32, device=dev)
+                    out = torch.empty_like(q)
+                    fn = lambda: ops.prefill_attention(q, k, v, cu, cu, 4096, 4096, D ** -0.5, out=out, tile_order=order)
+                    for _ in range(30):
+                        fn()
+                    torch.cuda.synchronize()
+                    t = timeit(fn, iters=50, warmup=2)
+                    r = dict(kind="prefill", ms=round(t * 1e3, 3), dropped=ops.STATS["tile_order_dropped"])
+                r["order"] = name
+                rows.append(r)
     if args.what == "prefill_order2":    # small grids: kernels x KV runs under a host-built table
         ops.reserve_decode_workspace(dev, 1 << 30)
         for lens, Hq, Hkv in (([4096] * 4, 4, 1), ([4096] * 2, 8, 2), ([4096] * 4, 8, 1), ([2048] * 8, 4, 1)):
