@@ -120,3 +120,37 @@ def test_planned_decode_under_graph_replay(gpu):
         ref = decode_ref(case["q"], case["k_cache"], case["v_cache"], case["context_lens"], case["block_table"], case["scale"])
         err = (out.float().cpu() - ref).abs().max().item()
         assert err <= TOL, f"max-abs {err}"
+
+
+def test_planned_decode_outlier_batch_at_full_size(gpu):
+    """The bench's outlier batch at its own size (256 sequences of 1..1024 tokens, four of them 16384,
+    32q/8kv): a size-independent property - permuting the physical blocks (and the block table with
+    them) leaves every output bit in place - plus the long sequences and a few short ones against the
+    oracle, and the plan's shape (the long ones cut, the short ones not)."""
+    from light_vllm_amd import ops
+    from light_vllm_amd.decode_plan import build_plan, worth_planning
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, 1025, (256,), generator=g).tolist()
+    for j in (3, 77, 130, 201):
+        lens[j] = 16384
+    Hq, Hkv = 32, 8
+    assert worth_planning(lens, Hkv, Hq // Hkv)
+    case = make_decode_case(31, lens, Hq, Hkv, extra_blocks=0)
+    d = to_dev(case, gpu)
+    plan = build_plan(lens, Hkv, Hq // Hkv).to(gpu)
+    splits = plan.seq_splits.tolist()
+    assert all(splits[j] >= 8 for j in (3, 77, 130, 201)) and sum(1 for s in splits if s > 1) == 4
+    out = ops.decode_attention(*_args(d), plan=plan)
+    nblk = d["k_cache"].size(0)
+    perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(1)).to(gpu)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nblk, device=gpu)
+    k2, v2 = d["k_cache"][perm], d["v_cache"][perm]
+    bt2 = inv[d["block_table"].long()].to(torch.int32)
+    out2 = ops.decode_attention(d["q"], k2, v2, d["context_lens"], bt2, d["scale"], plan=plan)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    rows = [3, 201, 0, 255]
+    sub = {k: (v[rows] if k in ("q", "context_lens", "block_table") else v) for k, v in case.items()}
+    ref = decode_ref(sub["q"], sub["k_cache"], sub["v_cache"], sub["context_lens"], sub["block_table"], sub["scale"])
+    assert (out[rows].float().cpu() - ref).abs().max().item() <= TOL
