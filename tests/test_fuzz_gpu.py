@@ -1,6 +1,6 @@
 """Randomised shape sweep: the HIP decode and prefill kernels against the CPU fp32 oracle on
 seeded random combinations of batch size, lengths (short, block-boundary and long), head
-grouping, block size, split count, launch order and kernel choice — the corners between the
+grouping, block size, split count, launch order, host-built work lists and tile tables, and kernel choice — the corners between the
 hand-picked cases of the other GPU tests. Tolerance as there: max-abs <= 2e-2 on bf16 outputs."""
 import os
 
@@ -46,8 +46,19 @@ def test_fuzz_decode(gpu, monkeypatch, seed):
     order = None
     if torch.rand((), generator=g).item() < 0.5:
         order = torch.tensor(sorted(range(B), key=lambda j: -lens[j]), dtype=torch.int32, device=gpu)
+    # a third of the cases run from a host-built work list instead (pieces of a random size, a random
+    # cap on pieces per sequence, spare capacity); drawn from a generator of its own, so that the
+    # cases above stay what they were before work lists existed
+    g2 = torch.Generator().manual_seed(5000 + seed)
+    plan = None
+    if torch.rand((), generator=g2).item() < 0.34:
+        from light_vllm_amd.decode_plan import build_plan
+        plan = build_plan(lens, Hkv, Hq // Hkv,
+                          max_splits=[1, 3, 64][int(torch.randint(0, 3, (), generator=g2))],
+                          piece_tokens=[0, 64, 128, 320][int(torch.randint(0, 4, (), generator=g2))],
+                          capacity=[0, 4 * B + 7][int(torch.randint(0, 2, (), generator=g2))]).to(gpu)
     out = ops.decode_attention(d["q"], d["k_cache"], d["v_cache"], d["context_lens"], d["block_table"], d["scale"],
-                               num_splits=ns, seq_order=order)
+                               num_splits=ns, seq_order=order, plan=plan)
     torch.cuda.synchronize()
     ref = decode_ref(case["q"], case["k_cache"], case["v_cache"], case["context_lens"], case["block_table"], case["scale"])
     err = (out.float().cpu() - ref).abs().max().item()
@@ -76,9 +87,19 @@ def test_fuzz_prefill(gpu, monkeypatch, seed):
     ns = [0, 0, 1, 2, 3, 5, 8][int(torch.randint(0, 7, (), generator=g))]
     case = make_prefill_case(4000 + seed, lens_q, lens_k, Hq, Hkv, block_size=block, paged=paged)
     d = to_dev(case, gpu)
+    # four cases in ten launch from a host-built tile table (forced for every head count); with the
+    # long-prompt kernel in one pass, half of those from an item table (its persistent form)
+    g2 = torch.Generator().manual_seed(6000 + seed)
+    tile_order = None
+    if torch.rand((), generator=g2).item() < 0.4:
+        persistent = cfg == "2" and ns == 1 and torch.rand((), generator=g2).item() < 0.5
+        tile_order = ops.prefill_tile_order(lens_q, lens_k, Hq, Hkv, gpu, num_splits=ns, force=True, paged=paged,
+                                            persistent=persistent)
+    dropped = ops.STATS["tile_order_dropped"]
     out = ops.prefill_attention(d["q"], d["k"], d["v"], d["cu_q"], d["cu_k"], d["max_q"], d["max_k"], d["scale"],
-                                block_table=d["block_table"], num_splits=ns)
+                                block_table=d["block_table"], num_splits=ns, tile_order=tile_order)
     torch.cuda.synchronize()
+    assert ops.STATS["tile_order_dropped"] == dropped, "a table planned for this very launch was not used"
     ref = prefill_ref(case["q"], case["k"], case["v"], case["cu_q"], case["cu_k"], case["scale"], case["block_table"])
     err = (out.float().cpu() - ref).abs().max().item()
     assert err <= TOL, f"seed {seed}: Hq/Hkv {Hq}/{Hkv} cfg {cfg} runs {ns} paged {paged} block {block} lens {lens_q}/{lens_k}: max-abs {err}"
