@@ -712,6 +712,9 @@ void prefill_attn_kernel(const PrefillParams p) {
 #ifndef LV_PP_LPRIO
 #define LV_PP_LPRIO 2
 #endif
+#ifndef LV_PP_SKIP
+#define LV_PP_SKIP 1   // a wave leaves out the tiles that hold no key any of its rows may see (0: every wave walks every tile)
+#endif
 // PERSIST (launched when the caller passes an item table, PrefillParams::order_lanes > 0): one
 // workgroup per compute unit walks a list of query tiles the host has balanced for it instead of
 // ending after one. What a workgroup pays per tile shrinks to reading its Q fragments and storing its
@@ -821,13 +824,16 @@ void prefill_pp_kernel(const PrefillParams p) {
     kref = PAGED ? tw.b : k_start;
   }
   // derived per query tile
-  int wlim0, my_lim, ntiles;
+  int wlim0, my_lim, ntiles, wtiles;
   table_ptr bt_row;
   auto derive = [&]() {
     wlim0 = lim0 + wave * 32;              // causal limit of the wave's first row
     my_lim = wlim0 + (fresh_lane() & 31);
     const int max_key = min(lim0 + nrows - 1, Lk - 1);
     ntiles = max_key >= 0 ? max_key / BN + 1 : 0;
+    // key tiles in which some row of THIS wave sees a key: on the workgroup's last tiles (its
+    // diagonal block) the waves that own its upper rows have nothing left to add
+    wtiles = (LV_PP_SKIP && wlim0 + 31 >= 0) ? min(ntiles, (wlim0 + 31) / BN + 1) : ntiles;
     bt_row = PAGED ? block_table + static_cast<int64_t>(kref) * p.bt_stride : nullptr;
   };
   derive();
@@ -1254,6 +1260,32 @@ void prefill_pp_kernel(const PrefillParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // One tile interval of a wave that has nothing to compute any more: its share of the staging, and
+  // the interval's four barriers.
+  auto stage_only = [&](int i, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int NPAR = PAR ^ 1;
+    __builtin_amdgcn_s_setprio(LV_PP_LPRIO);
+    if (i + 2 < ntiles) {
+      write_k(IntC<kKOff + PAR * kKStep>{}, kreg);
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(i + 3, p.k, k_row_bytes, st_koff, kreg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wg_barrier();
+    wg_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < ntiles) {
+      write_rows(IntC<kVOff + NPAR * kVStep>{}, vreg);
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(i + 2, p.v, v_row_bytes, st_voff, vreg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wg_barrier();
+    wg_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // Q fragments out of the wave's Q image (landed and waited for by this wave)
   auto read_q = [&]() {
     bf16x8 qtmp[8];
@@ -1275,13 +1307,24 @@ void prefill_pp_kernel(const PrefillParams p) {
     // K(0) published, K(1) and V(0) in flight (L_K(-1) publishes K(1), L_V(-1) V(0))
     LV_CLOCK_BEGIN
     body(-1, IntC<1>{}, IntC<0>{});
-    // Every interval also forms the scores of tile i+1; past the last tile they are computed from
-    // stale LDS and fully masked (every key of tile ntiles lies beyond every row's causal limit),
+    // Every interval also forms the scores of tile i+1; past the wave's last tile they are computed
+    // from stale LDS and fully masked (every key of that tile lies beyond every row's causal limit),
     // which leaves the running statistics untouched and keeps the loop body free of branches
-    // around its matrix clusters.
-    for (int i = 0; i < ntiles; i += 2) {
+    // around its matrix clusters. (An interval variant without that next tile, for the wave's last
+    // one, measured no faster and spilled.)
+    // A wave walks only the tiles that hold a key some row of it may see (wtiles of the workgroup's
+    // ntiles: on the diagonal block the waves of the upper rows are done early). For the rest it
+    // keeps its share of the staging and the four barriers of every interval, but reads no
+    // fragments, issues no MFMAs and takes no exponentials: those tiles' probabilities were exact
+    // zeros, so the result is the same to the bit, and the chip, which runs this kernel at its power
+    // limit, is spared the work (4 x 4096 tokens, 32q/8kv, same box, alternating runs: 0.566 -> 0.548 ms).
+    for (int i = 0; i < wtiles; i += 2) {
       body(i, IntC<0>{}, IntC<1>{});
-      if (i + 1 < ntiles) body(i + 1, IntC<1>{}, IntC<1>{});
+      if (i + 1 < wtiles) body(i + 1, IntC<1>{}, IntC<1>{});
+    }
+    for (int i = wtiles; i < ntiles; ++i) {
+      if (i & 1) stage_only(i, IntC<1>{});
+      else stage_only(i, IntC<0>{});
     }
     if (grp == 0) wg_barrier();
     LV_CLOCK_END
